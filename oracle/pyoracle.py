@@ -1,0 +1,275 @@
+"""ctypes bindings for the CPU checkers under oracle/.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product package (tinman_sandbox_amd/) never does.
+
+  Oracle      -> oracle/libcaar_oracle.so   (this repo's C restatement, caar_oracle.c)
+  Reference   -> oracle/_ref/libref_caar_np<NP>_nlev<NLEV>.so (the reference's own
+                 C++ path compiled from /root/reference by oracle/Makefile)
+
+Arrays are passed as a dict name -> contiguous float64 numpy array, names and
+order being the members of Homme::Arrays
+(compute_and_apply_rhs_test/cxx/pointers_only/data_structures.hpp:18-44).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+ARRAY_NAMES = (
+    "elem_D", "elem_Dinv", "elem_fcor", "elem_spheremp", "elem_metdet", "elem_rmetdet",
+    "elem_state_dp3d", "elem_state_v", "elem_state_T", "elem_state_phis", "elem_state_Qdp",
+    "elem_derived_eta_dot_dpdn", "elem_derived_omega_p", "elem_derived_phi",
+    "elem_derived_pecnd", "elem_derived_vn0",
+)
+
+_dp = C.POINTER(C.c_double)
+
+
+def array_shapes(np_, nlev, qsize_d, timelevels, ne):
+    """Element-major C layouts, data_structures.cpp:14-31."""
+    return {
+        "elem_D": (ne, np_, np_, 2, 2),
+        "elem_Dinv": (ne, np_, np_, 2, 2),
+        "elem_fcor": (ne, np_, np_),
+        "elem_spheremp": (ne, np_, np_),
+        "elem_metdet": (ne, np_, np_),
+        "elem_rmetdet": (ne, np_, np_),
+        "elem_state_dp3d": (ne, timelevels, nlev, np_, np_),
+        "elem_state_v": (ne, timelevels, nlev, np_, np_, 2),
+        "elem_state_T": (ne, timelevels, nlev, np_, np_),
+        "elem_state_phis": (ne, np_, np_),
+        "elem_state_Qdp": (ne, qsize_d, 2, nlev, np_, np_),
+        "elem_derived_eta_dot_dpdn": (ne, nlev + 1, np_, np_),
+        "elem_derived_omega_p": (ne, nlev, np_, np_),
+        "elem_derived_phi": (ne, nlev, np_, np_),
+        "elem_derived_pecnd": (ne, nlev, np_, np_),
+        "elem_derived_vn0": (ne, nlev, np_, np_, 2),
+    }
+
+
+def alloc_arrays(np_, nlev, qsize_d, timelevels, ne):
+    return {k: np.zeros(s, dtype=np.float64)
+            for k, s in array_shapes(np_, nlev, qsize_d, timelevels, ne).items()}
+
+
+class _OracleArrays(C.Structure):
+    _fields_ = [(n, _dp) for n in ARRAY_NAMES]
+
+
+class _OracleParams(C.Structure):
+    _fields_ = [
+        ("np", C.c_int), ("nlev", C.c_int), ("qsize_d", C.c_int), ("timelevels", C.c_int),
+        ("nets", C.c_int), ("nete", C.c_int),
+        ("n0", C.c_int), ("np1", C.c_int), ("nm1", C.c_int), ("qn0", C.c_int),
+        ("dt2", C.c_double),
+        ("rrearth", C.c_double), ("eta_ave_w", C.c_double), ("Rwater_vapor", C.c_double),
+        ("Rgas", C.c_double), ("kappa", C.c_double),
+        ("ps0", C.c_double), ("hyai0", C.c_double),
+        ("Dvv", _dp),
+    ]
+
+
+def _ptr(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp)
+
+
+def default_scalars(nlev):
+    """Constants/Control/HVCoord::init_data, data_structures.cpp:117-150."""
+    Rgas, cp = 287.04, 1005.0
+    return dict(nets=0, nete=None, n0=0, np1=1, nm1=2, qn0=0, dt2=1.0,
+                rrearth=1.0 / 6.376e6, eta_ave_w=1.0, Rwater_vapor=461.5, Rgas=Rgas,
+                kappa=Rgas / cp, ps0=10.0,
+                hyai=np.array([nlev + 1 - i for i in range(nlev + 1)], dtype=np.float64))
+
+
+def build(ref=True):
+    """Compile the checkers (gcc / g++ / flang) via oracle/Makefile."""
+    subprocess.run(["make", "-C", HERE, "liboracle"], check=True, capture_output=True)
+    if ref and os.path.isdir("/root/reference/compute_and_apply_rhs_test"):
+        subprocess.run(["make", "-C", HERE, "ref"], check=True, capture_output=True)
+
+
+class Oracle:
+    """This repo's C restatement (oracle/caar_oracle.c)."""
+
+    def __init__(self, path=None):
+        path = path or os.path.join(HERE, "libcaar_oracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        L = self.lib = C.CDLL(path)
+        L.oracle_compute_and_apply_rhs.argtypes = [C.POINTER(_OracleArrays), C.POINTER(_OracleParams)]
+        L.oracle_compute_and_apply_rhs.restype = C.c_int
+        L.oracle_state_norms.argtypes = [C.POINTER(_OracleArrays), C.POINTER(_OracleParams), _dp]
+        L.oracle_compute_norm.argtypes = [_dp, C.c_long]
+        L.oracle_compute_norm.restype = C.c_double
+        L.oracle_init_arrays.argtypes = [C.POINTER(_OracleArrays)] + [C.c_int] * 5
+        L.oracle_init_dvv_np4.argtypes = [_dp, C.c_int]
+        L.oracle_init_dvv_gll.argtypes = [C.c_int, _dp]
+        L.oracle_gradient_sphere.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, _dp]
+        L.oracle_divergence_sphere.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp]
+        L.oracle_vorticity_sphere.argtypes = [C.c_int, _dp, _dp, _dp, _dp, C.c_double, _dp]
+
+    @staticmethod
+    def _arrays(arrs):
+        return _OracleArrays(*[_ptr(arrs[n]) for n in ARRAY_NAMES])
+
+    def _params(self, arrs, Dvv, sc):
+        ne, tl, nlev, np_, _ = arrs["elem_state_dp3d"].shape
+        qd = arrs["elem_state_Qdp"].shape[1]
+        nete = ne if sc.get("nete") is None else sc["nete"]
+        self._keep = np.ascontiguousarray(Dvv, dtype=np.float64)
+        return _OracleParams(np_, nlev, qd, tl, sc["nets"], nete, sc["n0"], sc["np1"], sc["nm1"],
+                             sc["qn0"], sc["dt2"], sc["rrearth"], sc["eta_ave_w"],
+                             sc["Rwater_vapor"], sc["Rgas"], sc["kappa"], sc["ps0"],
+                             float(sc["hyai"][0]), _ptr(self._keep))
+
+    def compute_and_apply_rhs(self, arrs, Dvv, sc):
+        a, p = self._arrays(arrs), self._params(arrs, Dvv, sc)
+        rc = self.lib.oracle_compute_and_apply_rhs(C.byref(a), C.byref(p))
+        if rc != 0:
+            raise RuntimeError("oracle_compute_and_apply_rhs rc=%d" % rc)
+
+    def state_norms(self, arrs, Dvv, sc):
+        out = np.zeros(3)
+        a, p = self._arrays(arrs), self._params(arrs, Dvv, sc)
+        self.lib.oracle_state_norms(C.byref(a), C.byref(p), _ptr(out))
+        return out
+
+    def compute_norm(self, field):
+        f = np.ascontiguousarray(field, dtype=np.float64).ravel()
+        return self.lib.oracle_compute_norm(_ptr(f), f.size)
+
+    def init_arrays(self, np_, nlev, qsize_d, timelevels, ne):
+        arrs = alloc_arrays(np_, nlev, qsize_d, timelevels, ne)
+        a = self._arrays(arrs)
+        self.lib.oracle_init_arrays(C.byref(a), np_, nlev, qsize_d, timelevels, ne)
+        return arrs
+
+    def dvv_np4(self, f32_rounded=False):
+        d = np.zeros((4, 4))
+        self.lib.oracle_init_dvv_np4(_ptr(d), int(f32_rounded))
+        return d
+
+    def dvv_gll(self, np_):
+        d = np.zeros((np_, np_))
+        self.lib.oracle_init_dvv_gll(np_, _ptr(d))
+        return d
+
+    def gradient_sphere(self, s, Dvv, Dinv, rrearth):
+        np_ = s.shape[0]
+        out = np.zeros((np_, np_, 2))
+        self.lib.oracle_gradient_sphere(np_, _ptr(np.ascontiguousarray(s)), _ptr(np.ascontiguousarray(Dvv)),
+                                        _ptr(np.ascontiguousarray(Dinv)), rrearth, _ptr(out))
+        return out
+
+    def divergence_sphere(self, v, Dvv, Dinv, metdet, rmetdet, rrearth):
+        np_ = v.shape[0]
+        out = np.zeros((np_, np_))
+        self.lib.oracle_divergence_sphere(np_, _ptr(np.ascontiguousarray(v)), _ptr(np.ascontiguousarray(Dvv)),
+                                          _ptr(np.ascontiguousarray(Dinv)), _ptr(np.ascontiguousarray(metdet)),
+                                          _ptr(np.ascontiguousarray(rmetdet)), rrearth, _ptr(out))
+        return out
+
+    def vorticity_sphere(self, v, Dvv, D, rmetdet, rrearth):
+        np_ = v.shape[0]
+        out = np.zeros((np_, np_))
+        self.lib.oracle_vorticity_sphere(np_, _ptr(np.ascontiguousarray(v)), _ptr(np.ascontiguousarray(Dvv)),
+                                         _ptr(np.ascontiguousarray(D)), _ptr(np.ascontiguousarray(rmetdet)),
+                                         rrearth, _ptr(out))
+        return out
+
+
+def ref_lib_path(np_, nlev):
+    return os.path.join(HERE, "_ref", "libref_caar_np%d_nlev%d.so" % (np_, nlev))
+
+
+def have_reference(np_=4, nlev=72):
+    return os.path.exists(ref_lib_path(np_, nlev))
+
+
+class Reference:
+    """The reference's own C++ path (oracle/_ref/, built by oracle/Makefile from
+    /root/reference; qsize_d=1, timelevels=3 are fixed by its config.h.in)."""
+
+    def __init__(self, np_=4, nlev=72):
+        self.np, self.nlev = np_, nlev
+        L = self.lib = C.CDLL(ref_lib_path(np_, nlev))
+        dims = (C.c_int * 4)()
+        L.ref_dims(dims)
+        assert (dims[0], dims[1]) == (np_, nlev)
+        self.qsize_d, self.timelevels = dims[2], dims[3]
+        pp = _dp * 16
+        L.ref_compute_and_apply_rhs.argtypes = ([pp] + [C.c_int] * 6 + [C.c_double] * 7 + [_dp, _dp])
+        L.ref_init_data.argtypes = [C.c_int, pp, _dp, _dp, _dp]
+        L.ref_sphere_operator.argtypes = [C.c_int, _dp, _dp, pp, C.c_int, C.c_double, _dp]
+        L.ref_compute_norm.argtypes = [_dp, C.c_int]
+        L.ref_compute_norm.restype = C.c_double
+
+    @staticmethod
+    def _pp(arrs):
+        return (_dp * 16)(*[_ptr(arrs[n]) for n in ARRAY_NAMES])
+
+    def compute_and_apply_rhs(self, arrs, Dvv, sc):
+        ne = arrs["elem_state_dp3d"].shape[0]
+        nete = ne if sc.get("nete") is None else sc["nete"]
+        Dvv = np.ascontiguousarray(Dvv, dtype=np.float64)
+        hyai = np.ascontiguousarray(sc["hyai"], dtype=np.float64)
+        assert hyai.size == self.nlev + 1 and Dvv.size == self.np ** 2
+        self.lib.ref_compute_and_apply_rhs(self._pp(arrs), sc["nets"], nete, sc["n0"], sc["np1"],
+                                           sc["nm1"], sc["qn0"], sc["dt2"], sc["rrearth"],
+                                           sc["eta_ave_w"], sc["Rwater_vapor"], sc["Rgas"],
+                                           sc["kappa"], sc["ps0"], _ptr(hyai), _ptr(Dvv))
+
+    def init_data(self, ne):
+        arrs = alloc_arrays(self.np, self.nlev, self.qsize_d, self.timelevels, ne)
+        scal = np.zeros(12)
+        hyai = np.zeros(self.nlev + 1)
+        Dvv = np.zeros((self.np, self.np))
+        self.lib.ref_init_data(ne, self._pp(arrs), _ptr(scal), _ptr(hyai), _ptr(Dvv))
+        sc = dict(nets=0, nete=None, n0=int(scal[8]), np1=int(scal[9]), nm1=int(scal[10]),
+                  qn0=int(scal[11]), dt2=scal[6], rrearth=scal[0], eta_ave_w=scal[1],
+                  Rwater_vapor=scal[3], Rgas=scal[4], kappa=scal[5], ps0=scal[7], hyai=hyai)
+        return arrs, Dvv, sc
+
+    def sphere_operator(self, which, x, arrs, ie, rrearth, Dvv):
+        np_ = self.np
+        out = np.zeros((np_, np_, 2) if which == 0 else (np_, np_))
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        Dvv = np.ascontiguousarray(Dvv, dtype=np.float64)
+        self.lib.ref_sphere_operator(which, _ptr(x), _ptr(out), self._pp(arrs), ie, rrearth, _ptr(Dvv))
+        return out
+
+    def compute_norm(self, field):
+        f = np.ascontiguousarray(field, dtype=np.float64).ravel()
+        return self.lib.ref_compute_norm(_ptr(f), f.size)
+
+
+def run_fortran_driver(arrs, Dvv, sc):
+    """Run oracle/_ref/fortran_driver (reference Fortran routine_mod, NP=4 NLEV=72,
+    physical constants fixed by physical_constants.F90) on `arrs`; returns the
+    mutated arrays.  `arrs` itself is left untouched."""
+    import tempfile
+    exe = os.path.join(HERE, "_ref", "fortran_driver")
+    ne = arrs["elem_state_dp3d"].shape[0]
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            np.array([ne, sc["n0"], sc["np1"], sc["nm1"], sc["qn0"]], dtype=np.int32).tofile(f)
+            np.array([sc["dt2"], sc["eta_ave_w"], sc["ps0"]], dtype=np.float64).tofile(f)
+            np.ascontiguousarray(sc["hyai"], dtype=np.float64).tofile(f)
+            np.ascontiguousarray(Dvv, dtype=np.float64).tofile(f)
+            for n in ARRAY_NAMES:
+                arrs[n].tofile(f)
+        subprocess.run([exe, fin, fout], check=True)
+        out = {}
+        with open(fout, "rb") as f:
+            for n in ("elem_state_dp3d", "elem_state_v", "elem_state_T",
+                      "elem_derived_eta_dot_dpdn", "elem_derived_omega_p",
+                      "elem_derived_phi", "elem_derived_vn0"):
+                out[n] = np.fromfile(f, dtype=np.float64, count=arrs[n].size).reshape(arrs[n].shape)
+    return out

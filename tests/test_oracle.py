@@ -1,0 +1,147 @@
+"""Pins oracle/caar_oracle.c (the CPU parity checker) to the reference.
+
+ 1. the reference's own golden vectors Ttest/v1test/v2test (fortran/test_mod.F90:8-882,
+    checked the way fortran/main.F90:241-274 checks them),
+ 2. committed outputs of the reference C++ path (cxx/pointers_only) and Fortran routine
+    (fortran/routine_mod.F90) for every case in tests/cases.py (tests/golden/*.npz,
+    produced by tests/golden/make_golden.py from oracle/_ref),
+ 3. when oracle/_ref is present (build container), the live reference library,
+    operator by operator.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import pyoracle as po
+
+
+def run_oracle(oracle, name):
+    arrs, Dvv, sc = cases.make_case(name)
+    out = cases.copy_arrays(arrs)
+    oracle.compute_and_apply_rhs(out, Dvv, sc)
+    return arrs, out, sc
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_oracle_matches_reference_cxx_bitwise(oracle, name):
+    """Same operand order + no FMA contraction => bit-identical to g++ -O3 reference."""
+    arrs, out, sc = run_oracle(oracle, name)
+    gold = cases.load_golden(name)
+    for n in cases.OUTPUT_NAMES:
+        got = out[n][:, sc["np1"]] if n.startswith("elem_state_") else out[n]
+        assert np.array_equal(got, gold[n]), n
+    # nothing but np1 / the derived accumulators may change
+    for n in po.ARRAY_NAMES:
+        if n.startswith("elem_state_") and n in cases.OUTPUT_NAMES:
+            for t in range(3):
+                if t != sc["np1"]:
+                    assert np.array_equal(out[n][:, t], arrs[n][:, t]), (n, t)
+        elif n not in cases.OUTPUT_NAMES:
+            assert np.array_equal(out[n], arrs[n]), n
+
+
+@pytest.mark.parametrize("name", [n for n in cases.CASES if os.path.exists(cases.golden_path(n))])
+def test_oracle_matches_reference_fortran(oracle, name):
+    gold = cases.load_golden(name)
+    if "f90_elem_state_T" not in gold:
+        pytest.skip("no Fortran build of the reference for this configuration")
+    c = cases.CASES[name]
+    arrs, Dvv, sc = cases.make_case(name)
+    sc["nets"], sc["nete"] = 0, None  # the Fortran fixture covers every element
+    out = cases.copy_arrays(arrs)
+    oracle.compute_and_apply_rhs(out, Dvv, sc)
+    for n in cases.OUTPUT_NAMES:
+        got = out[n][:, sc["np1"]] if n.startswith("elem_state_") else out[n]
+        # flang -O2 and gcc agree to rounding; 1e-13 leaves room for association
+        # differences (derivative_mod_base.F90:119,228 scale by (rmetdet*rrearth))
+        assert cases.scaled_err(got, gold["f90_" + n]) <= 1e-13, (n, c)
+
+
+def test_reference_golden_vectors_test_mod(oracle):
+    """fortran/main.F90:241-274: element 1, time level np1, index i + np*(j-1) + np*np*(k-1),
+    f32-rounded Dvv.  The reference accepts 'T diff 0, V diff 5.1e-13' (its own stdout,
+    tests/golden/fortran_orig_stdout.txt)."""
+    with np.load(os.path.join(cases.GOLDEN_DIR, "fortran_test_mod_vectors.npz")) as z:
+        Tt, v1t, v2t = z["Ttest"], z["v1test"], z["v2test"]
+    arrs, out, sc = run_oracle(oracle, "np4_nlev72_closed_f32dvv")
+    # golden order: i fastest, then j, then k  <->  C++ [k][i][j]  => transpose in-level
+    T = out["elem_state_T"][0, sc["np1"]].transpose(0, 2, 1).ravel()
+    v1 = out["elem_state_v"][0, sc["np1"], ..., 0].transpose(0, 2, 1).ravel()
+    v2 = out["elem_state_v"][0, sc["np1"], ..., 1].transpose(0, 2, 1).ravel()
+    assert np.max(np.abs(T - Tt)) == 0.0
+    assert np.max(np.abs(v1 - v1t)) <= 5.2e-13
+    assert np.max(np.abs(v2 - v2t)) <= 5.2e-13
+    assert cases.rel_err(v1, v1t) <= 1e-14 and cases.rel_err(v2, v2t) <= 1e-14
+
+
+def test_reference_driver_norms(oracle):
+    """The norms the reference drivers print (P:372-399, main.F90:168-194,278-304)."""
+    txt = open(os.path.join(cases.GOLDEN_DIR, "fortran_orig_stdout.txt")).read().split()
+    vals = [float(txt[i + 2]) for i, w in enumerate(txt) if w.startswith("||")]
+    before, after = vals[:3], vals[3:6]
+    arrs, Dvv, sc = cases.make_case("np4_nlev72_closed_f32dvv")
+    assert np.allclose(oracle.state_norms(arrs, Dvv, sc), before, rtol=1e-15, atol=0)
+    oracle.compute_and_apply_rhs(arrs, Dvv, sc)
+    assert np.allclose(oracle.state_norms(arrs, Dvv, sc), after, rtol=2e-16, atol=0)
+
+
+def test_idempotent_state_and_doubling_accumulators(oracle):
+    """calling twice gives the same np1 state and doubles the increments."""
+    arrs, Dvv, sc = cases.make_case("np4_nlev72_hashed")
+    a1 = cases.copy_arrays(arrs)
+    oracle.compute_and_apply_rhs(a1, Dvv, sc)
+    a2 = cases.copy_arrays(a1)
+    oracle.compute_and_apply_rhs(a2, Dvv, sc)
+    for n in ("elem_state_v", "elem_state_T", "elem_state_dp3d", "elem_derived_phi"):
+        assert np.array_equal(a1[n], a2[n])
+    inc1 = a1["elem_derived_vn0"] - arrs["elem_derived_vn0"]
+    inc2 = a2["elem_derived_vn0"] - a1["elem_derived_vn0"]
+    assert cases.scaled_err(inc2, inc1) < 1e-12
+
+
+def test_gll_matrix_reproduces_np4_literals(oracle):
+    assert np.max(np.abs(oracle.dvv_gll(4) - oracle.dvv_np4())) < 2e-15
+    D8 = oracle.dvv_gll(8)
+    # derivative of a constant vanishes; exact for polynomials up to degree 7
+    assert np.max(np.abs(D8.sum(axis=1))) < 1e-13
+
+
+needs_ref = pytest.mark.skipif(not po.have_reference(4, 72),
+                               reason="oracle/_ref not built (needs /root/reference)")
+
+
+@needs_ref
+@pytest.mark.parametrize("np_,nlev", [(4, 72), (8, 72)])
+def test_live_reference_operators(oracle, np_, nlev):
+    R = po.Reference(np_, nlev)
+    arrs = cases.hashed_arrays(np_, nlev, 2, seed=11)
+    Dvv = cases.dvv_for(np_, "double" if np_ == 4 else "gll")
+    rr = 0.37
+    for ie in range(2):
+        s = cases.uniform((np_, np_), 77 + ie, -3, 5)
+        v = cases.uniform((np_, np_, 2), 99 + ie, -3, 5)
+        g = oracle.gradient_sphere(s, Dvv, arrs["elem_Dinv"][ie], rr)
+        d = oracle.divergence_sphere(v, Dvv, arrs["elem_Dinv"][ie], arrs["elem_metdet"][ie],
+                                     arrs["elem_rmetdet"][ie], rr)
+        w = oracle.vorticity_sphere(v, Dvv, arrs["elem_D"][ie], arrs["elem_rmetdet"][ie], rr)
+        assert np.array_equal(g, R.sphere_operator(0, s, arrs, ie, rr, Dvv))
+        assert np.array_equal(d, R.sphere_operator(1, v, arrs, ie, rr, Dvv))
+        assert np.array_equal(w, R.sphere_operator(2, v, arrs, ie, rr, Dvv))
+
+
+@needs_ref
+def test_live_reference_init_and_norm(oracle):
+    R = po.Reference(4, 72)
+    arrs_r, Dvv_r, sc_r = R.init_data(5)
+    arrs_o = oracle.init_arrays(4, 72, 1, 3, 5)
+    for n in po.ARRAY_NAMES:
+        assert np.array_equal(arrs_r[n], arrs_o[n]), n
+    assert np.array_equal(Dvv_r, oracle.dvv_np4(False))
+    sc = po.default_scalars(72)
+    for k in ("n0", "np1", "nm1", "qn0", "dt2", "rrearth", "eta_ave_w", "Rwater_vapor", "Rgas", "kappa", "ps0"):
+        assert sc[k] == sc_r[k], k
+    assert np.array_equal(sc["hyai"], sc_r["hyai"])
+    f = arrs_o["elem_state_v"][0, 1]
+    assert oracle.compute_norm(f) == R.compute_norm(f)
