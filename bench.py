@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: element-RHS-updates/s of compute_and_apply_rhs on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one compute_and_apply_rhs call over every element resident on the GPU
+(BASELINE.json configs[1]: NP=4, NLEV=72, 10 000 elements per GPU, fp64, moist
+branch, the reference's closed-form synthetic arrays).  Elements shard
+embarrassingly: every rank owns a contiguous slab of the global element range and
+there is no data-path collective (weak scaling: 10 000 elements per GPU).
+
+Rank 0 prints ONE JSON line: metric/value (whole-job element updates per second),
+"roofline" for the dominant kernel (algorithmic bytes per launch / HIP-event
+kernel time, against the 8 TB/s HBM3E peak) and "cpu_baseline" (the reference's
+own serial C++ path, or this repo's C port of it, on the host cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--np", type=int, default=4, dest="np_")
+    ap.add_argument("--nlev", type=int, default=72)
+    ap.add_argument("--elems-per-gpu", type=int, default=10000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=1.5,
+                    help="target wall seconds per host thread for the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(np_, nlev, seconds):
+    """Times the CPU path on the host cores: oracle/_ref (the reference's own C++,
+    kind "reference") when it was built, else oracle/caar_oracle.c (kind "port").
+    Each thread owns a private slab + Control range, the reference's own sharding
+    hook (data_structures.hpp:58-69)."""
+    import numpy as np
+    from oracle import pyoracle as po
+    cores = len(os.sched_getaffinity(0))
+    use_ref = po.have_reference(np_, nlev)
+    O = po.Oracle()
+    per_thread = 256
+    Dvv = O.dvv_np4(False) if np_ == 4 else O.dvv_gll(np_)
+    sc = po.default_scalars(nlev)
+
+    def make_runner():
+        arrs = O.init_arrays(np_, nlev, 1, 3, per_thread)
+        if use_ref:
+            R = po.Reference(np_, nlev)
+            return lambda: R.compute_and_apply_rhs(arrs, Dvv, sc)
+        o = po.Oracle()
+        return lambda: o.compute_and_apply_rhs(arrs, Dvv, sc)
+
+    # calibrate repetitions on one thread
+    run = make_runner()
+    run()
+    t0 = time.perf_counter()
+    run()
+    dt = time.perf_counter() - t0
+    reps = max(1, int(seconds / max(dt, 1e-6)))
+    single = per_thread / dt
+
+    runners = [make_runner() for _ in range(cores)]
+    for r in runners:
+        r()  # touch memory
+    barrier = threading.Barrier(cores + 1)
+
+    def work(r):
+        barrier.wait()
+        for _ in range(reps):
+            r()
+        barrier.wait()
+
+    ths = [threading.Thread(target=work, args=(r,)) for r in runners]
+    for t in ths:
+        t.start()
+    barrier.wait()
+    t0 = time.perf_counter()
+    barrier.wait()
+    wall = time.perf_counter() - t0
+    for t in ths:
+        t.join()
+    return {
+        "value": cores * per_thread * reps / wall,
+        "unit": "element-updates/s",
+        "cores": cores,
+        "kind": "reference" if use_ref else "port",
+        "single_core_value": single,
+        "sample": "%d threads x %d elements x %d calls of %s, NP=%d NLEV=%d, wall %.2fs" % (
+            cores, per_thread, reps,
+            "oracle/_ref (reference cxx/pointers_only, g++ -O3)" if use_ref else "oracle/caar_oracle.c (gcc -O2)",
+            np_, nlev, wall),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import tinman_sandbox_amd as tsa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs MI355X GPUs (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- this rank's slab of the global element range -------------------------------
+    total_elems = args.elems_per_gpu * world
+    nets, nete = tsa.shard_range(total_elems, rank, world)
+    data = tsa.TestData().init_data(nete - nets, args.np_, args.nlev, device=dev, first_elem=nets)
+    stream = torch.cuda.current_stream(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        tsa.compute_and_apply_rhs(data, stream)
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        tsa.compute_and_apply_rhs(data, stream)
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
+
+    tmax = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall_max, kernel_ms_max = tmax.tolist()
+
+    if rank == 0:
+        balg = tsa.algorithmic_bytes(args.np_, args.nlev)
+        per_launch_bytes = balg * (nete - nets)
+        achieved = per_launch_bytes / (kernel_ms_max * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(prof):
+            try:
+                j = json.load(open(prof))
+                key = "np%d_nlev%d_e%d" % (args.np_, args.nlev, nete - nets)
+                traffic = j.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "element-RHS-updates/sec (node) + achieved HBM GB/s, NP=%d NLEV=%d fp64" % (args.np_, args.nlev),
+            "value": total_elems * args.steps / wall_max,
+            "unit": "element-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "compute_and_apply_rhs NP=%d NLEV=%d num_elems=%d per GPU (%d total), moist, "
+                            "reference closed-form element arrays" % (args.np_, args.nlev, args.elems_per_gpu, total_elems),
+                "parallelism": "element-sharded x%d, no collectives" % world,
+                "kernel": tsa.library().lib.caar_kernel_name(args.np_, args.nlev).decode(),
+            },
+            "hbm_gbs_algorithmic_job": total_elems * args.steps * balg / wall_max / 1e9,
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_element": balg,
+                "elements_per_launch": nete - nets,
+                "kernel_ms": kernel_ms_max,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.np_, args.nlev, args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+/*
+ * caar.h — C ABI of the MI355X (gfx950) compute_and_apply_rhs implementation.
+ *
+ * libcaar_hip.so is the drop-in boundary for the reference's hot path
+ *     namespace Homme { void compute_and_apply_rhs(TestData& data); }
+ *     (compute_and_apply_rhs_test/cxx/pointers_only/compute_and_apply_rhs.hpp:9,
+ *      Fortran twin fortran/routine_mod.F90:7)
+ * The reference has no FFI layer of its own; these entry points are
+ * what a binding for that one function needs: plain pointers, ints and doubles,
+ * no C++ or torch types, no exceptions.  Every function returns 0 on success, a
+ * positive hipError_t value if the HIP runtime failed, or a negative CAAR_E* code.
+ *
+ * Data layout is the reference's element-major C++ layout, unchanged
+ * (data_structures.hpp:18-44, data_structures.cpp:14-31), so a host that already
+ * owns a Homme::Arrays can pass its 16 pointers as they are:
+ *     elem_D, elem_Dinv                          [ie][np][np][2][2]
+ *     elem_fcor, spheremp, metdet, rmetdet       [ie][np][np]
+ *     elem_state_dp3d, elem_state_T              [ie][timelevels][nlev][np][np]
+ *     elem_state_v                               [ie][timelevels][nlev][np][np][2]
+ *     elem_state_phis                            [ie][np][np]
+ *     elem_state_Qdp                             [ie][qsize_d][2][nlev][np][np]
+ *     elem_derived_eta_dot_dpdn                  [ie][nlev+1][np][np]
+ *     elem_derived_omega_p, phi, pecnd           [ie][nlev][np][np]
+ *     elem_derived_vn0                           [ie][nlev][np][np][2]
+ */
+#ifndef CAAR_H
+#define CAAR_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAAR_ABI_VERSION 1
+
+enum {
+  CAAR_OK = 0,
+  CAAR_EINVAL = -1,       /* null pointer, bad index or range */
+  CAAR_EUNSUPPORTED = -2, /* (np, nlev) has no compiled kernel: see caar_supported() */
+  CAAR_ENODEVICE = -3,    /* no HIP device / wrong architecture */
+  CAAR_ENOMEM = -4
+};
+
+/* The 16 element arrays.  Member order == Homme::Arrays
+ * (data_structures.hpp:18-44).  Pointers are host or device pointers depending on
+ * the call (stated per function). */
+typedef struct CaarArrays {
+  double *elem_D;
+  double *elem_Dinv;
+  double *elem_fcor;
+  double *elem_spheremp;
+  double *elem_metdet;
+  double *elem_rmetdet;
+  double *elem_state_dp3d;
+  double *elem_state_v;
+  double *elem_state_T;
+  double *elem_state_phis;
+  double *elem_state_Qdp;
+  double *elem_derived_eta_dot_dpdn;
+  double *elem_derived_omega_p;
+  double *elem_derived_phi;
+  double *elem_derived_pecnd;
+  double *elem_derived_vn0;
+} CaarArrays;
+#define CAAR_NUM_ARRAYS 16
+
+/* Compile-time dimensions of the reference (dimensions.hpp:9-15 via config.h),
+ * run-time here. */
+typedef struct CaarDims {
+  int np;         /* GLL points per element edge: 4 or 8            */
+  int nlev;       /* vertical levels (PLEV)                          */
+  int qsize_d;    /* tracer slots in elem_state_Qdp (>= 1)           */
+  int timelevels; /* time levels in elem_state_* (reference: 3)      */
+  int num_elems;  /* elements the arrays hold                         */
+} CaarDims;
+
+/* Homme::Control (data_structures.hpp:58-69) + Constants (:46-56) + the parts of
+ * HVCoord (:10-16) and Derivative (:71-76) the path reads.  All host values. */
+typedef struct CaarParams {
+  int nets, nete;      /* element range [nets, nete), 0-based (Control::nets/nete)   */
+  int n0, np1, nm1;    /* 0-based time-level indices                                 */
+  int qn0;             /* Qdp time slot (0/1), or -1 for the dry branch (P:128)      */
+  double dt2;
+  double rrearth;      /* Constants::rrearth                                         */
+  double eta_ave_w;
+  double Rwater_vapor;
+  double Rgas;
+  double kappa;
+  double ps0;          /* HVCoord::ps0                                               */
+  double hyai0;        /* HVCoord::hyai[0], the only hyai entry the path reads (P:84) */
+  const double *Dvv;   /* HOST pointer, np*np doubles, row-major Dvv[i][j]           */
+} CaarParams;
+
+/* 1 if a kernel is compiled for (np, nlev), else 0. */
+int caar_supported(int np, int nlev);
+/* CAAR_ABI_VERSION the library was built with. */
+int caar_abi_version(void);
+/* Static text for a return code. */
+const char *caar_strerror(int rc);
+/* Number of doubles in array `index` (0..15, CaarArrays member order) for `dims`,
+ * or -1. */
+long long caar_array_len(const CaarDims *dims, int index);
+/* Algorithmic HBM bytes one element update moves:
+ * 8*(21*np^2*nlev + 2*np^2*(nlev+1) + 13*np^2); the dry branch reads one block less. */
+long long caar_algorithmic_bytes(int np, int nlev, int dry);
+
+/* ---- stateless launch on device-resident arrays -------------------------------
+ * Replaces one call of Homme::compute_and_apply_rhs (P:15) for elements
+ * [params->nets, params->nete).  `dev` holds DEVICE pointers to arrays in the
+ * layout above (e.g. torch tensors or hipMalloc'd buffers); `stream` is a
+ * hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing.
+ * `dvv_dev` is a DEVICE buffer of np*np doubles holding params->Dvv (the caller
+ * uploads it once; params->Dvv is ignored here).  No allocation, no
+ * synchronisation, safe to capture in a hipGraph. */
+int caar_launch(const CaarDims *dims, const CaarArrays *dev, const double *dvv_dev,
+                const CaarParams *params, void *stream);
+
+/* print_results_2norm's per-element arithmetic (P:353-390) on device-resident arrays:
+ * out_dev[3*(e-e0)+f] = pow(compute_norm(field_f of element e at time level tl), 2),
+ * f = 0,1,2 for v, T, dp3d.  `out_dev` is a DEVICE buffer of 3*(e1-e0) doubles.
+ * Asynchronous on `stream`; the caller sums over elements and takes the root (P:394-396). */
+int caar_launch_state_norms(const CaarDims *dims, const CaarArrays *dev, int tl, int e0, int e1,
+                            double *out_dev, void *stream);
+
+/* Name of the kernel caar_launch dispatches for (np, nlev) (for profiles), or NULL. */
+const char *caar_kernel_name(int np, int nlev);
+
+/* ---- context API: the library owns the device copies ---------------------------
+ * What Homme::compute_and_apply_rhs(TestData&) needs when TestData lives in host
+ * memory (Arrays::init_data, data_structures.cpp:14-31). */
+typedef struct CaarContext CaarContext;
+
+/* Allocates device storage for dims->num_elems elements on HIP device `device`
+ * and a private stream. */
+int caar_create(CaarContext **ctx, const CaarDims *dims, int device);
+void caar_destroy(CaarContext *ctx);
+/* Host -> device copy of all 16 arrays for elements [e0, e1) (element-major layout:
+ * one contiguous range per array).  `host` = pointers to element 0 of host arrays
+ * holding at least e1 elements. Asynchronous on the context stream. */
+int caar_upload(CaarContext *ctx, const CaarArrays *host, int e0, int e1);
+/* Device -> host copy of the arrays the path mutates (state_v/T/dp3d, eta_dot_dpdn,
+ * omega_p, phi, vn0) for elements [e0, e1); all_arrays != 0 copies all 16. */
+int caar_download(CaarContext *ctx, const CaarArrays *host, int e0, int e1, int all_arrays);
+/* Enqueue one compute_and_apply_rhs on the context's device arrays
+ * (params->Dvv is read from host memory and cached on the device). */
+int caar_run(CaarContext *ctx, const CaarParams *params);
+/* Wait for everything enqueued on the context stream. */
+int caar_sync(CaarContext *ctx);
+/* Device pointers / stream of the context (for callers that launch their own work). */
+int caar_device_arrays(CaarContext *ctx, CaarArrays *out);
+void *caar_stream(CaarContext *ctx);
+/* print_results_2norm's arithmetic on the device (P:372-399): out[0..2] =
+ * ||v||_2, ||T||_2, ||dp3d||_2 of time level `tl` over elements [e0, e1), Kahan sum
+ * of squares per element as compute_norm (P:353-370).  Synchronous. */
+int caar_state_norms(CaarContext *ctx, int tl, int e0, int e1, double out[3]);
+/* Time `reps` back-to-back caar_run calls with hipEvents on the context stream;
+ * *ms_total receives the elapsed milliseconds.  Synchronous. */
+int caar_time_runs(CaarContext *ctx, const CaarParams *params, int reps, float *ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAAR_H */

@@ -1,0 +1,125 @@
+"""CPU-side tests of the host logic and of the C-ABI library's surface (no GPU:
+nothing here launches a kernel)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import pyoracle as po
+
+import tinman_sandbox_amd as tsa
+from tinman_sandbox_amd import build as tbuild
+from tinman_sandbox_amd import caar as m
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    tbuild.build_library()
+    return tsa.library()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    """Every function include/caar.h declares is exported by libcaar_hip.so."""
+    hdr = open(os.path.join(ROOT, "include", "caar.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(caar_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(m.CaarLibrary.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib.lib, s), s
+    assert lib.lib.caar_abi_version() == 1
+
+
+def test_supported_variants_and_names(lib):
+    assert lib.lib.caar_supported(4, 72) == 1
+    assert lib.lib.caar_supported(4, 128) == 1
+    assert lib.lib.caar_supported(5, 72) == 0
+    assert b"caar" in lib.lib.caar_kernel_name(4, 72)
+    assert lib.lib.caar_kernel_name(3, 3) is None
+    assert lib.lib.caar_strerror(-2).decode().startswith("no kernel")
+
+
+@pytest.mark.parametrize("np_,nlev,ne", [(4, 72, 3), (4, 128, 2), (8, 72, 5)])
+def test_array_lengths_and_algorithmic_bytes(lib, np_, nlev, ne):
+    dims = m._CaarDims(np_, nlev, 1, 3, ne)
+    shapes = tsa.array_shapes(np_, nlev, 1, 3, ne)
+    for i, n in enumerate(tsa.ARRAY_NAMES):
+        assert lib.lib.caar_array_len(C.byref(dims), i) == int(np.prod(shapes[n])), n
+    assert lib.lib.caar_array_len(C.byref(dims), 16) == -1
+    assert lib.lib.caar_algorithmic_bytes(np_, nlev, 0) == tsa.algorithmic_bytes(np_, nlev)
+    assert lib.lib.caar_algorithmic_bytes(np_, nlev, 1) == tsa.algorithmic_bytes(np_, nlev, dry=True)
+    # SURVEY.md 8d table
+    assert tsa.algorithmic_bytes(4, 72) == 213888
+    assert tsa.algorithmic_bytes(4, 128) == 378752
+    assert tsa.algorithmic_bytes(8, 72) == 855552
+
+
+def test_launch_validates_without_touching_a_device(lib):
+    """Argument errors are detected before any HIP call (safe on a CPU-only box)."""
+    dims = m._CaarDims(4, 72, 1, 3, 4)
+    prm = m._CaarParams(0, 5, 0, 1, 2, 0, 1.0, 1.0, 1.0, 461.5, 287.04, 0.28, 10.0, 73.0, None)
+    ptrs = m._CaarArrays()
+    assert lib.lib.caar_launch(C.byref(dims), C.byref(ptrs), None, C.byref(prm), None) == -1  # nete > num_elems
+    prm.nete = 4
+    assert lib.lib.caar_launch(C.byref(dims), C.byref(ptrs), None, C.byref(prm), None) == -1  # null arrays
+    dims2 = m._CaarDims(6, 72, 1, 3, 4)
+    fake = m._CaarArrays(*[C.cast(64, m._dp)] * 16)
+    assert lib.lib.caar_launch(C.byref(dims2), C.byref(fake), C.c_void_p(64), C.byref(prm), None) == -2
+    assert lib.lib.caar_launch(None, None, None, None, None) == -1
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(m.CaarError, match="no CPU fallback"):
+        m.CaarLibrary(str(tmp_path / "nope.so"))
+
+
+def test_cpu_arrays_are_refused():
+    d = tsa.TestData().init_data(2, 4, 72, device="cpu")
+    with pytest.raises(m.CaarError, match="no CPU fallback"):
+        tsa.compute_and_apply_rhs(d)
+
+
+@pytest.mark.parametrize("np_,nlev", [(4, 72), (4, 128), (8, 72)])
+def test_closed_form_init_matches_oracle_init(oracle, np_, nlev):
+    """ElementArrays.init_data == Arrays::init_data (data_structures.cpp:42-92)."""
+    ne = 3
+    mine = tsa.ElementArrays(np_, nlev, ne, device="cpu").init_data().to_numpy()
+    ref = oracle.init_arrays(np_, nlev, 1, 3, ne)
+    for n in tsa.ARRAY_NAMES:
+        assert np.array_equal(mine[n], ref[n]), n
+    # a rank's slab [first, first+n) is the matching slice of the global arrays
+    slab = tsa.ElementArrays(np_, nlev, 2, device="cpu").init_data(first_elem=1).to_numpy()
+    for n in tsa.ARRAY_NAMES:
+        assert np.array_equal(slab[n], ref[n][1:3]), n
+
+
+def test_reference_scalars_and_dvv(oracle):
+    d = tsa.TestData().init_data(2, 4, 72, device="cpu")
+    sc = po.default_scalars(72)
+    assert (d.control.n0, d.control.np1, d.control.nm1, d.control.qn0) == (0, 1, 2, 0)
+    for k in ("rrearth", "eta_ave_w", "Rwater_vapor", "Rgas", "kappa"):
+        assert getattr(d.constants, k) == sc[k]
+    assert d.hvcoord.ps0 == sc["ps0"] and np.array_equal(d.hvcoord.hyai, sc["hyai"])
+    assert np.array_equal(d.deriv.Dvv, oracle.dvv_np4(False))
+    assert np.array_equal(tsa.Derivative(4, f32_rounded=True).Dvv, oracle.dvv_np4(True))
+    assert np.max(np.abs(tsa.gll_derivative_matrix(4) - oracle.dvv_np4(False))) < 2e-15
+    assert np.max(np.abs(tsa.gll_derivative_matrix(8) - oracle.dvv_gll(8))) < 5e-14
+    d.update_time_levels()  # data_structures.cpp:174-180
+    assert (d.control.n0, d.control.np1, d.control.nm1) == (1, 2, 0)
+
+
+def test_shard_range_partitions_exactly():
+    for E, G in [(10000, 1), (100000, 8), (10, 3), (5, 8), (64, 2)]:
+        seen = []
+        for r in range(G):
+            a, b = tsa.shard_range(E, r, G)
+            assert 0 <= a <= b <= E
+            seen += list(range(a, b))
+        assert seen == list(range(E))
+    assert tsa.shard_range(100000, 3, 8) == (37500, 50000)

@@ -1,0 +1,8 @@
+"""MI355X-native compute_and_apply_rhs (HOMME CAAR) — host-side Python surface.
+
+The product is the HIP library (csrc/, C ABI in include/caar.h); this package is
+the thin host layer the tests and bench.py drive it through.
+"""
+from .caar import (ARRAY_NAMES, CaarLibrary, Constants, Control, Derivative, ElementArrays,  # noqa: F401
+                   HVCoord, TestData, algorithmic_bytes, array_shapes, compute_and_apply_rhs,
+                   gll_derivative_matrix, library, print_results_2norm, shard_range, state_norms)

@@ -1,0 +1,433 @@
+"""Host-side mirror of the reference's interface for compute_and_apply_rhs, on top of
+the C ABI (include/caar.h, csrc/libcaar_hip.so).
+
+Names follow the reference's C++ driver so that tests read like its own code:
+  TestData{arrays, constants, control, deriv, hvcoord}, init_data(),
+  update_time_levels(), compute_and_apply_rhs(data), print_results_2norm(data)
+  (compute_and_apply_rhs_test/cxx/pointers_only/data_structures.hpp:10-89,
+   compute_and_apply_rhs.hpp:9-22, main.cpp:96-131).
+
+torch is used for what it is good at here — owning device memory and streams —
+and nothing else: the arithmetic runs in the hand-written HIP kernels.  There is
+no CPU fallback: without the built library or without a GPU the calls raise.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import torch  # imported BEFORE the HIP library is loaded so both share one HIP runtime
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcaar_hip.so")
+
+# member order of Homme::Arrays (data_structures.hpp:18-44) == CaarArrays
+ARRAY_NAMES = (
+    "elem_D", "elem_Dinv", "elem_fcor", "elem_spheremp", "elem_metdet", "elem_rmetdet",
+    "elem_state_dp3d", "elem_state_v", "elem_state_T", "elem_state_phis", "elem_state_Qdp",
+    "elem_derived_eta_dot_dpdn", "elem_derived_omega_p", "elem_derived_phi",
+    "elem_derived_pecnd", "elem_derived_vn0",
+)
+MUTATED = ("elem_state_dp3d", "elem_state_v", "elem_state_T", "elem_derived_eta_dot_dpdn",
+           "elem_derived_omega_p", "elem_derived_phi", "elem_derived_vn0")
+
+_dp = C.POINTER(C.c_double)
+
+
+class _CaarArrays(C.Structure):
+    _fields_ = [(n, _dp) for n in ARRAY_NAMES]
+
+
+class _CaarDims(C.Structure):
+    _fields_ = [("np", C.c_int), ("nlev", C.c_int), ("qsize_d", C.c_int),
+                ("timelevels", C.c_int), ("num_elems", C.c_int)]
+
+
+class _CaarParams(C.Structure):
+    _fields_ = [("nets", C.c_int), ("nete", C.c_int), ("n0", C.c_int), ("np1", C.c_int),
+                ("nm1", C.c_int), ("qn0", C.c_int), ("dt2", C.c_double), ("rrearth", C.c_double),
+                ("eta_ave_w", C.c_double), ("Rwater_vapor", C.c_double), ("Rgas", C.c_double),
+                ("kappa", C.c_double), ("ps0", C.c_double), ("hyai0", C.c_double), ("Dvv", _dp)]
+
+
+class CaarError(RuntimeError):
+    pass
+
+
+class CaarLibrary:
+    """ctypes view of libcaar_hip.so; every symbol of include/caar.h is bound here."""
+
+    SYMBOLS = ("caar_supported", "caar_abi_version", "caar_strerror", "caar_array_len",
+               "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms",
+               "caar_kernel_name", "caar_create", "caar_destroy", "caar_upload", "caar_download",
+               "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
+               "caar_time_runs")
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise CaarError(
+                "HIP extension %s is missing: build it with `python -m tinman_sandbox_amd.build` "
+                "(there is no CPU fallback)" % path)
+        L = self.lib = C.CDLL(path)
+        for s in self.SYMBOLS:
+            getattr(L, s)  # AttributeError if the library does not export it
+        vp = C.c_void_p
+        L.caar_supported.argtypes = [C.c_int, C.c_int]
+        L.caar_strerror.argtypes = [C.c_int]
+        L.caar_strerror.restype = C.c_char_p
+        L.caar_array_len.argtypes = [C.POINTER(_CaarDims), C.c_int]
+        L.caar_array_len.restype = C.c_longlong
+        L.caar_algorithmic_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.caar_algorithmic_bytes.restype = C.c_longlong
+        L.caar_launch.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays), vp,
+                                  C.POINTER(_CaarParams), vp]
+        L.caar_launch_state_norms.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays), C.c_int,
+                                              C.c_int, C.c_int, vp, vp]
+        L.caar_kernel_name.argtypes = [C.c_int, C.c_int]
+        L.caar_kernel_name.restype = C.c_char_p
+        L.caar_create.argtypes = [C.POINTER(vp), C.POINTER(_CaarDims), C.c_int]
+        L.caar_destroy.argtypes = [vp]
+        L.caar_destroy.restype = None
+        L.caar_upload.argtypes = [vp, C.POINTER(_CaarArrays), C.c_int, C.c_int]
+        L.caar_download.argtypes = [vp, C.POINTER(_CaarArrays), C.c_int, C.c_int, C.c_int]
+        L.caar_run.argtypes = [vp, C.POINTER(_CaarParams)]
+        L.caar_sync.argtypes = [vp]
+        L.caar_device_arrays.argtypes = [vp, C.POINTER(_CaarArrays)]
+        L.caar_stream.argtypes = [vp]
+        L.caar_stream.restype = vp
+        L.caar_state_norms.argtypes = [vp, C.c_int, C.c_int, C.c_int, _dp]
+        L.caar_time_runs.argtypes = [vp, C.POINTER(_CaarParams), C.c_int, C.POINTER(C.c_float)]
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise CaarError("%s failed: rc=%d (%s)" % (what, rc, self.lib.caar_strerror(rc).decode()))
+
+
+_LIB = None
+
+
+def library():
+    global _LIB
+    if _LIB is None:
+        _LIB = CaarLibrary()
+    return _LIB
+
+
+# ----------------------------------------------------------------------------- layout
+def array_shapes(np_, nlev, qsize_d, timelevels, num_elems):
+    """Element-major layouts of Arrays::init_data, data_structures.cpp:14-31."""
+    ne = num_elems
+    return {
+        "elem_D": (ne, np_, np_, 2, 2),
+        "elem_Dinv": (ne, np_, np_, 2, 2),
+        "elem_fcor": (ne, np_, np_),
+        "elem_spheremp": (ne, np_, np_),
+        "elem_metdet": (ne, np_, np_),
+        "elem_rmetdet": (ne, np_, np_),
+        "elem_state_dp3d": (ne, timelevels, nlev, np_, np_),
+        "elem_state_v": (ne, timelevels, nlev, np_, np_, 2),
+        "elem_state_T": (ne, timelevels, nlev, np_, np_),
+        "elem_state_phis": (ne, np_, np_),
+        "elem_state_Qdp": (ne, qsize_d, 2, nlev, np_, np_),
+        "elem_derived_eta_dot_dpdn": (ne, nlev + 1, np_, np_),
+        "elem_derived_omega_p": (ne, nlev, np_, np_),
+        "elem_derived_phi": (ne, nlev, np_, np_),
+        "elem_derived_pecnd": (ne, nlev, np_, np_),
+        "elem_derived_vn0": (ne, nlev, np_, np_, 2),
+    }
+
+
+def algorithmic_bytes(np_, nlev, dry=False):
+    """bytes one element update must move (inputs once, outputs once, RMW twice)."""
+    pp = np_ * np_
+    return 8 * ((20 if dry else 21) * pp * nlev + 2 * pp * (nlev + 1) + 13 * pp)
+
+
+def shard_range(num_elems, rank, world_size):
+    """Contiguous element slab [nets, nete) of `rank`: ceil(E/G) elements
+    per rank, the last ranks may get fewer (or none)."""
+    per = -(-num_elems // world_size)
+    nets = min(rank * per, num_elems)
+    return nets, min(nets + per, num_elems)
+
+
+class ElementArrays:
+    """The 16 element arrays (Homme::Arrays) as torch float64 tensors on one device."""
+
+    def __init__(self, np_, nlev, num_elems, qsize_d=1, timelevels=3, device="cpu", tensors=None):
+        self.np, self.nlev, self.num_elems = np_, nlev, num_elems
+        self.qsize_d, self.timelevels = qsize_d, timelevels
+        self.device = torch.device(device)
+        shapes = array_shapes(np_, nlev, qsize_d, timelevels, num_elems)
+        if tensors is None:
+            tensors = {n: torch.zeros(s, dtype=torch.float64, device=self.device) for n, s in shapes.items()}
+        for n in ARRAY_NAMES:
+            t = tensors[n]
+            assert tuple(t.shape) == shapes[n] and t.dtype == torch.float64 and t.is_contiguous(), n
+        self.t = tensors
+
+    def __getitem__(self, name):
+        return self.t[name]
+
+    @classmethod
+    def from_numpy(cls, arrs, device="cpu"):
+        ne, tl, nlev, np_, _ = arrs["elem_state_dp3d"].shape
+        qd = arrs["elem_state_Qdp"].shape[1]
+        tens = {n: torch.from_numpy(np.ascontiguousarray(arrs[n])).to(device) for n in ARRAY_NAMES}
+        return cls(np_, nlev, ne, qd, tl, device, tens)
+
+    def to_numpy(self):
+        return {n: self.t[n].detach().cpu().numpy().copy() for n in ARRAY_NAMES}
+
+    def to(self, device):
+        return ElementArrays(self.np, self.nlev, self.num_elems, self.qsize_d, self.timelevels, device,
+                             {n: self.t[n].to(device) for n in ARRAY_NAMES})
+
+    def clone(self):
+        return ElementArrays(self.np, self.nlev, self.num_elems, self.qsize_d, self.timelevels,
+                             self.device, {n: self.t[n].clone() for n in ARRAY_NAMES})
+
+    def nbytes(self):
+        return sum(t.numel() * 8 for t in self.t.values())
+
+    def dims(self):
+        return _CaarDims(self.np, self.nlev, self.qsize_d, self.timelevels, self.num_elems)
+
+    def pointers(self):
+        return _CaarArrays(*[C.cast(self.t[n].data_ptr(), _dp) for n in ARRAY_NAMES])
+
+    def init_data(self, first_elem=0):
+        """The reference's closed-form initialiser (Arrays::init_data, data_structures.cpp:42-92
+        == fortran/main.F90:103-154).  `first_elem` is the global index of local element 0,
+        so that a rank holding the slab [nets, nete) builds exactly its part of the global
+        arrays.  The three transcendental tables are formed with libm (math.sin/cos), like
+        the reference, then broadcast on the device."""
+        np_, nlev, ne, tl = self.np, self.nlev, self.num_elems, self.timelevels
+        dev, f64 = self.device, torch.float64
+        ip = torch.arange(1, np_ + 1, dtype=f64, device=dev).view(np_, 1)   # iip
+        jp = torch.arange(1, np_ + 1, dtype=f64, device=dev).view(1, np_)   # jjp
+        il = torch.arange(1, nlev + 1, dtype=f64, device=dev).view(nlev, 1, 1)
+        iie = (torch.arange(ne, dtype=f64, device=dev) + (first_elem + 1))
+        fcor = torch.tensor([[math.sin(i + j) for j in range(1, np_ + 1)] for i in range(1, np_ + 1)],
+                            dtype=f64, device=dev)
+        phi0 = torch.tensor([[math.cos(i + 3 * j) for j in range(1, np_ + 1)] for i in range(1, np_ + 1)],
+                            dtype=f64, device=dev)
+        qdp0 = torch.tensor([[[1.0 + math.sin(float(i * j * l)) for j in range(1, np_ + 1)]
+                              for i in range(1, np_ + 1)] for l in range(1, nlev + 1)], dtype=f64, device=dev)
+        t = self.t
+        t["elem_fcor"][:] = fcor
+        t["elem_metdet"][:] = ip * jp
+        t["elem_rmetdet"][:] = 1.0 / (ip * jp)
+        t["elem_spheremp"][:] = (2 * ip).expand(np_, np_)
+        t["elem_state_phis"][:] = ip + jp
+        t["elem_D"].zero_()
+        t["elem_D"][..., 0, 0] = 1.0
+        t["elem_D"][..., 1, 1] = 2.0
+        t["elem_Dinv"].zero_()
+        t["elem_Dinv"][..., 0, 0] = 1.0
+        t["elem_Dinv"][..., 1, 1] = 0.5
+        t["elem_derived_phi"][:] = phi0 + il
+        t["elem_derived_vn0"].fill_(1.0)
+        t["elem_derived_pecnd"].fill_(1.0)
+        t["elem_derived_omega_p"][:] = (jp * jp).expand(np_, np_)
+        t["elem_derived_eta_dot_dpdn"].zero_()
+        t["elem_state_Qdp"].zero_()
+        t["elem_state_Qdp"][:, 0, 0] = qdp0
+        e = iie.view(ne, 1, 1, 1, 1)
+        it = torch.arange(1, tl + 1, dtype=f64, device=dev).view(1, tl, 1, 1, 1)
+        l5, i5, j5 = il.view(1, 1, nlev, 1, 1), ip.view(1, 1, 1, np_, 1), jp.view(1, 1, 1, 1, np_)
+        # same operand order as data_structures.cpp:82-86
+        t["elem_state_dp3d"][:] = 10.0 * l5 + e + i5 + j5 + it
+        base = 1.0 + 0.5 * l5 + i5 + j5 + 0.2 * e
+        t["elem_state_v"][..., 0] = base + 2.0 * it
+        t["elem_state_v"][..., 1] = base + 3.0 * it
+        t["elem_state_T"][:] = 1000.0 - l5 - i5 - j5 + 0.1 * e + it
+        return self
+
+
+# ------------------------------------------------- reference structs (data_structures.hpp)
+class Constants:
+    """Constants::init_data, data_structures.cpp:117-127."""
+
+    def __init__(self):
+        self.Rwater_vapor = 461.5
+        self.Rgas = 287.04
+        self.cp = 1005.0
+        self.kappa = self.Rgas / self.cp
+        self.rrearth = 1.0 / 6.376e6
+        self.eta_ave_w = 1.0
+
+
+class Control:
+    """Control::init_data, data_structures.cpp:129-139."""
+
+    def __init__(self, num_elems):
+        self.nets, self.nete = 0, num_elems
+        self.n0, self.np1, self.nm1, self.qn0 = 0, 1, 2, 0
+        self.dt2 = 1.0
+
+
+class HVCoord:
+    """HVCoord::init_data, data_structures.cpp:141-149."""
+
+    def __init__(self, nlev):
+        self.ps0 = 10.0
+        self.hyai = np.array([nlev + 1 - i for i in range(nlev + 1)], dtype=np.float64)
+
+
+NP4_DVV_VALUES = (
+    -3.0000000000000000, -0.80901699437494745, 0.30901699437494745, -0.50000000000000000,
+    4.0450849718747373, 0.00000000000000000, -1.11803398874989490, 1.54508497187473700,
+    -1.5450849718747370, 1.11803398874989490, 0.00000000000000000, -4.04508497187473730,
+    0.5000000000000000, -0.30901699437494745, 0.80901699437494745, 3.000000000000000000)
+
+
+def gll_derivative_matrix(np_):
+    """Dvv[i][j] = l_j'(x_i) on the np_-point Gauss-Lobatto-Legendre grid.  The reference
+    hard-codes the np=4 values only (Derivative::init_data, data_structures.cpp:152-162,
+    which this reproduces to rounding); np=8 needs a generated matrix."""
+    N = np_ - 1
+    x = -np.cos(np.pi * np.arange(np_) / N)
+    P = np.polynomial.legendre.Legendre.basis(N)
+    dP, d2P = P.deriv(), P.deriv(2)
+    for _ in range(100):  # Newton on P_N'(x) for the interior nodes
+        dx = dP(x[1:-1]) / d2P(x[1:-1])
+        x[1:-1] -= dx
+        if np.max(np.abs(dx)) < 1e-16:
+            break
+    x[0], x[-1] = -1.0, 1.0
+    L = P(x)
+    D = np.zeros((np_, np_))
+    for i in range(np_):
+        for j in range(np_):
+            if i != j:
+                D[i, j] = L[i] / (L[j] * (x[i] - x[j]))
+    D[0, 0] = -0.25 * N * (N + 1)
+    D[N, N] = 0.25 * N * (N + 1)
+    return D
+
+
+class Derivative:
+    """Derivative::init_data, data_structures.cpp:151-163 (np=4 literals), GLL otherwise."""
+
+    def __init__(self, np_, f32_rounded=False):
+        if np_ == 4:
+            vals = np.array(NP4_DVV_VALUES, dtype=np.float64)
+            if f32_rounded:  # the Fortran driver's single-precision literals, main.F90:83-96
+                vals = vals.astype(np.float32).astype(np.float64)
+            self.Dvv = np.ascontiguousarray(vals.reshape(4, 4).T)  # Dvv[i][j] = values[j*np + i]
+        else:
+            self.Dvv = gll_derivative_matrix(np_)
+
+
+class TestData:
+    """Homme::TestData, data_structures.hpp:78-89."""
+    __test__ = False  # not a pytest class
+
+    def __init__(self):
+        self.arrays = None
+        self.constants = None
+        self.control = None
+        self.deriv = None
+        self.hvcoord = None
+        self._dvv_dev = None
+        self._dvv_key = None
+
+    def init_data(self, num_elems, np_=4, nlev=72, device="cuda", first_elem=0):
+        """TestData::init_data, data_structures.cpp:165-172."""
+        self.arrays = ElementArrays(np_, nlev, num_elems, device=device).init_data(first_elem)
+        self.constants = Constants()
+        self.control = Control(num_elems)
+        self.hvcoord = HVCoord(nlev)
+        self.deriv = Derivative(np_)
+        return self
+
+    @classmethod
+    def from_numpy(cls, arrs, Dvv, scalars, device="cuda"):
+        """Wrap host arrays + the flat scalar dict used by the tests/oracle."""
+        d = cls()
+        d.arrays = ElementArrays.from_numpy(arrs, device)
+        d.constants = Constants()
+        for k in ("Rwater_vapor", "Rgas", "kappa", "rrearth", "eta_ave_w"):
+            setattr(d.constants, k, float(scalars[k]))
+        d.control = Control(d.arrays.num_elems)
+        for k in ("nets", "n0", "np1", "nm1", "qn0"):
+            setattr(d.control, k, int(scalars[k]))
+        if scalars.get("nete") is not None:
+            d.control.nete = int(scalars["nete"])
+        d.control.dt2 = float(scalars["dt2"])
+        d.hvcoord = HVCoord(d.arrays.nlev)
+        d.hvcoord.ps0 = float(scalars["ps0"])
+        d.hvcoord.hyai = np.ascontiguousarray(scalars["hyai"], dtype=np.float64)
+        d.deriv = Derivative(d.arrays.np)
+        d.deriv.Dvv = np.ascontiguousarray(Dvv, dtype=np.float64)
+        return d
+
+    def update_time_levels(self):
+        """TestData::update_time_levels, data_structures.cpp:174-180."""
+        c = self.control
+        c.np1, c.nm1, c.n0 = c.nm1, c.n0, c.np1
+
+    def dvv_device(self):
+        key = (self.deriv.Dvv.tobytes(), str(self.arrays.device))
+        if self._dvv_key != key:
+            self._dvv_dev = torch.from_numpy(np.ascontiguousarray(self.deriv.Dvv)).to(self.arrays.device)
+            self._dvv_key = key
+        return self._dvv_dev
+
+    def params(self):
+        c, k, h = self.control, self.constants, self.hvcoord
+        self._dvv_host = np.ascontiguousarray(self.deriv.Dvv, dtype=np.float64)
+        return _CaarParams(c.nets, c.nete, c.n0, c.np1, c.nm1, c.qn0, c.dt2, k.rrearth, k.eta_ave_w,
+                           k.Rwater_vapor, k.Rgas, k.kappa, h.ps0, float(h.hyai[0]),
+                           self._dvv_host.ctypes.data_as(_dp))
+
+
+def _require_gpu(arrays):
+    if arrays.device.type != "cuda":
+        raise CaarError("compute_and_apply_rhs runs on the MI355X only: arrays live on %s "
+                        "(there is no CPU fallback)" % arrays.device)
+
+
+def compute_and_apply_rhs(data, stream=None):
+    """Homme::compute_and_apply_rhs(TestData&), compute_and_apply_rhs.hpp:9 — one
+    asynchronous launch on `stream` (default: torch's current stream) over the
+    elements [control.nets, control.nete) of the device-resident arrays."""
+    L = library()
+    _require_gpu(data.arrays)
+    if stream is None:
+        stream = torch.cuda.current_stream(data.arrays.device)
+    dims, ptrs, prm = data.arrays.dims(), data.arrays.pointers(), data.params()
+    rc = L.lib.caar_launch(C.byref(dims), C.byref(ptrs), C.c_void_p(data.dvv_device().data_ptr()),
+                           C.byref(prm), C.c_void_p(stream.cuda_stream))
+    L.check(rc, "caar_launch")
+
+
+def state_norms(data, tl=None):
+    """(||v||, ||T||, ||dp3d||) of time level `tl` (default np1) over [nets, nete):
+    the arithmetic of print_results_2norm, P:372-399, evaluated on the device."""
+    L = library()
+    _require_gpu(data.arrays)
+    c = data.control
+    tl = c.np1 if tl is None else tl
+    n = c.nete - c.nets
+    out = torch.empty(max(n, 1) * 3, dtype=torch.float64, device=data.arrays.device)
+    stream = torch.cuda.current_stream(data.arrays.device)
+    dims, ptrs = data.arrays.dims(), data.arrays.pointers()
+    rc = L.lib.caar_launch_state_norms(C.byref(dims), C.byref(ptrs), tl, c.nets, c.nete,
+                                       C.c_void_p(out.data_ptr()), C.c_void_p(stream.cuda_stream))
+    L.check(rc, "caar_launch_state_norms")
+    per = out.cpu().numpy()[: 3 * n].reshape(n, 3)
+    s = [0.0, 0.0, 0.0]
+    for e in range(n):  # P:388-390: plain running sums in element order
+        for f in range(3):
+            s[f] += per[e, f]
+    return tuple(math.sqrt(x) for x in s)
+
+
+def print_results_2norm(data):
+    """P:392-396 output format."""
+    v, t, d = state_norms(data)
+    print("   ---> Norms:\n          ||v||_2  = %.17g\n          ||T||_2  = %.17g\n"
+          "          ||dp||_2 = %.17g" % (v, t, d))
+    return v, t, d

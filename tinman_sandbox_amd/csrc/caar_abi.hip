@@ -1,0 +1,313 @@
+// caar_abi.hip — the extern "C" boundary declared in include/caar.h.
+//
+// Thin: argument validation, kernel selection by (np, nlev), device bookkeeping
+// for the context API.  No CPU fallback: if no HIP device or no kernel for the
+// requested dimensions exists the call fails with an error code.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/caar.h"
+#include "caar_kernel_args.h"
+
+namespace caar {
+hipError_t launch_np4_nlev72(const KernelArgs& k, int num_elems, hipStream_t stream);
+hipError_t launch_np4_nlev128(const KernelArgs& k, int num_elems, hipStream_t stream);
+hipError_t launch_state_norms(const double* v, const double* T, const double* dp, int np, int nlev,
+                              int timelevels, int tl, int e0, int e1, double* out3_per_elem,
+                              hipStream_t stream);
+
+typedef hipError_t (*launch_fn)(const KernelArgs&, int, hipStream_t);
+struct Variant {
+  int np, nlev;
+  launch_fn fn;
+  const char* kernel;
+};
+static const Variant kVariants[] = {
+    {4, 72, launch_np4_nlev72, "caar_np4_kernel<72, 3>"},
+    {4, 128, launch_np4_nlev128, "caar_np4_kernel<128, 4>"},
+};
+static const Variant* find_variant(int np, int nlev) {
+  for (const Variant& v : kVariants)
+    if (v.np == np && v.nlev == nlev) return &v;
+  return nullptr;
+}
+}  // namespace caar
+
+struct CaarContext {
+  CaarDims dims;
+  int device;
+  hipStream_t stream;
+  CaarArrays dev;       // device pointers
+  double* dvv_dev;      // np*np
+  double dvv_host[64];  // last uploaded Dvv (re-upload only when it changes)
+  bool dvv_valid;
+  double* norms_dev;    // 3 * num_elems
+};
+
+static double** array_slot(CaarArrays* a, int i) { return reinterpret_cast<double**>(a) + i; }
+static double* const* array_slot(const CaarArrays* a, int i) {
+  return reinterpret_cast<double* const*>(a) + i;
+}
+// the arrays compute_and_apply_rhs writes (SURVEY.md 8b "mutated in place")
+static const int kMutated[] = {6, 7, 8, 11, 12, 13, 15};
+
+#define HIP_TRY(expr)                     \
+  do {                                    \
+    hipError_t e_ = (expr);               \
+    if (e_ != hipSuccess) return (int)e_; \
+  } while (0)
+
+extern "C" {
+
+int caar_abi_version(void) { return CAAR_ABI_VERSION; }
+
+int caar_supported(int np, int nlev) { return caar::find_variant(np, nlev) != nullptr; }
+
+const char* caar_kernel_name(int np, int nlev) {
+  const caar::Variant* v = caar::find_variant(np, nlev);
+  return v ? v->kernel : nullptr;
+}
+
+const char* caar_strerror(int rc) {
+  switch (rc) {
+    case CAAR_OK: return "ok";
+    case CAAR_EINVAL: return "invalid argument";
+    case CAAR_EUNSUPPORTED: return "no kernel compiled for this (np, nlev)";
+    case CAAR_ENODEVICE: return "no usable HIP device";
+    case CAAR_ENOMEM: return "out of memory";
+    default: return rc > 0 ? hipGetErrorString((hipError_t)rc) : "unknown caar error";
+  }
+}
+
+long long caar_array_len(const CaarDims* d, int i) {
+  if (!d || i < 0 || i >= CAAR_NUM_ARRAYS) return -1;
+  const long long ne = d->num_elems, pp = (long long)d->np * d->np, blk = pp * d->nlev;
+  switch (i) {
+    case 0: case 1: return ne * pp * 4;
+    case 2: case 3: case 4: case 5: case 9: return ne * pp;
+    case 6: case 8: return ne * d->timelevels * blk;
+    case 7: return ne * d->timelevels * blk * 2;
+    case 10: return ne * d->qsize_d * 2 * blk;
+    case 11: return ne * (blk + pp);
+    case 12: case 13: case 14: return ne * blk;
+    default: return ne * blk * 2;
+  }
+}
+
+long long caar_algorithmic_bytes(int np, int nlev, int dry) {
+  const long long pp = (long long)np * np;
+  return 8 * ((dry ? 20 : 21) * pp * nlev + 2 * pp * (nlev + 1) + 13 * pp);
+}
+
+static int check_common(const CaarDims* d, const CaarParams* p) {
+  if (!d || !p) return CAAR_EINVAL;
+  if (d->num_elems < 0 || d->qsize_d < 1 || d->timelevels < 1) return CAAR_EINVAL;
+  if (p->nets < 0 || p->nete > d->num_elems || p->nets > p->nete) return CAAR_EINVAL;
+  const int tl = d->timelevels;
+  if (p->n0 < 0 || p->n0 >= tl || p->np1 < 0 || p->np1 >= tl || p->nm1 < 0 || p->nm1 >= tl)
+    return CAAR_EINVAL;
+  if (p->qn0 < -1 || p->qn0 > 1) return CAAR_EINVAL;  // Qdp holds 2 time slots (data_structures.cpp:27)
+  return CAAR_OK;
+}
+
+int caar_launch(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev,
+                const CaarParams* p, void* stream) {
+  int rc = check_common(dims, p);
+  if (rc) return rc;
+  if (!dev || !dvv_dev) return CAAR_EINVAL;
+  for (int i = 0; i < CAAR_NUM_ARRAYS; ++i)
+    if (!*array_slot(dev, i)) return CAAR_EINVAL;
+  const caar::Variant* var = caar::find_variant(dims->np, dims->nlev);
+  if (!var) return CAAR_EUNSUPPORTED;
+  const int n = p->nete - p->nets;
+  if (n == 0) return CAAR_OK;
+
+  caar::KernelArgs k;
+  k.D = dev->elem_D;
+  k.Dinv = dev->elem_Dinv;
+  k.fcor = dev->elem_fcor;
+  k.spheremp = dev->elem_spheremp;
+  k.metdet = dev->elem_metdet;
+  k.rmetdet = dev->elem_rmetdet;
+  k.dp3d = dev->elem_state_dp3d;
+  k.v = dev->elem_state_v;
+  k.T = dev->elem_state_T;
+  k.phis = dev->elem_state_phis;
+  k.Qdp = dev->elem_state_Qdp;
+  k.eta_dot_dpdn = dev->elem_derived_eta_dot_dpdn;
+  k.omega_p = dev->elem_derived_omega_p;
+  k.phi = dev->elem_derived_phi;
+  k.pecnd = dev->elem_derived_pecnd;
+  k.vn0 = dev->elem_derived_vn0;
+  k.Dvv = dvv_dev;
+  k.nets = p->nets;
+  k.n0 = p->n0;
+  k.np1 = p->np1;
+  k.nm1 = p->nm1;
+  k.qn0 = p->qn0;
+  k.qsize_d = dims->qsize_d;
+  k.timelevels = dims->timelevels;
+  k.dt2 = p->dt2;
+  k.rrearth = p->rrearth;
+  k.eta_ave_w = p->eta_ave_w;
+  k.rv_over_rd_m1 = p->Rwater_vapor / p->Rgas - 1.0;  // P:151
+  k.Rgas = p->Rgas;
+  k.kappa = p->kappa;
+  k.p_top = p->hyai0 * p->ps0;  // P:84
+  return (int)var->fn(k, n, (hipStream_t)stream);
+}
+
+int caar_launch_state_norms(const CaarDims* d, const CaarArrays* dev, int tl, int e0, int e1,
+                            double* out_dev, void* stream) {
+  if (!d || !dev || !out_dev || tl < 0 || tl >= d->timelevels || e0 < 0 || e1 > d->num_elems || e0 > e1)
+    return CAAR_EINVAL;
+  if (!dev->elem_state_v || !dev->elem_state_T || !dev->elem_state_dp3d) return CAAR_EINVAL;
+  return (int)caar::launch_state_norms(dev->elem_state_v, dev->elem_state_T, dev->elem_state_dp3d, d->np,
+                                       d->nlev, d->timelevels, tl, e0, e1, out_dev, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ context API
+int caar_create(CaarContext** out, const CaarDims* dims, int device) {
+  if (!out || !dims || dims->num_elems <= 0) return CAAR_EINVAL;
+  if (!caar::find_variant(dims->np, dims->nlev)) return CAAR_EUNSUPPORTED;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CAAR_ENODEVICE;
+  if (device < 0 || device >= ndev) return CAAR_EINVAL;
+  HIP_TRY(hipSetDevice(device));
+  CaarContext* c = new (std::nothrow) CaarContext();
+  if (!c) return CAAR_ENOMEM;
+  std::memset(c, 0, sizeof(*c));
+  c->dims = *dims;
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  for (int i = 0; e == hipSuccess && i < CAAR_NUM_ARRAYS; ++i)
+    e = hipMalloc((void**)array_slot(&c->dev, i), sizeof(double) * caar_array_len(dims, i));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->dvv_dev, sizeof(double) * 64);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->norms_dev, sizeof(double) * 3 * dims->num_elems);
+  if (e != hipSuccess) {
+    caar_destroy(c);
+    return e == hipErrorOutOfMemory ? CAAR_ENOMEM : (int)e;
+  }
+  *out = c;
+  return CAAR_OK;
+}
+
+void caar_destroy(CaarContext* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int i = 0; i < CAAR_NUM_ARRAYS; ++i)
+    if (*array_slot(&c->dev, i)) (void)hipFree(*array_slot(&c->dev, i));
+  if (c->dvv_dev) (void)hipFree(c->dvv_dev);
+  if (c->norms_dev) (void)hipFree(c->norms_dev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+static int copy_range(CaarContext* c, const CaarArrays* host, int i, int e0, int e1, bool to_device) {
+  const long long per = caar_array_len(&c->dims, i) / c->dims.num_elems;
+  double* h = *array_slot(host, i);
+  double* d = *array_slot(&c->dev, i);
+  if (!h) return CAAR_EINVAL;
+  const size_t off = (size_t)per * e0, bytes = sizeof(double) * (size_t)per * (e1 - e0);
+  if (to_device) HIP_TRY(hipMemcpyAsync(d + off, h + off, bytes, hipMemcpyHostToDevice, c->stream));
+  else HIP_TRY(hipMemcpyAsync(h + off, d + off, bytes, hipMemcpyDeviceToHost, c->stream));
+  return CAAR_OK;
+}
+
+int caar_upload(CaarContext* c, const CaarArrays* host, int e0, int e1) {
+  if (!c || !host || e0 < 0 || e1 > c->dims.num_elems || e0 > e1) return CAAR_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  for (int i = 0; i < CAAR_NUM_ARRAYS; ++i) {
+    int rc = copy_range(c, host, i, e0, e1, true);
+    if (rc) return rc;
+  }
+  return CAAR_OK;
+}
+
+int caar_download(CaarContext* c, const CaarArrays* host, int e0, int e1, int all_arrays) {
+  if (!c || !host || e0 < 0 || e1 > c->dims.num_elems || e0 > e1) return CAAR_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  if (all_arrays) {
+    for (int i = 0; i < CAAR_NUM_ARRAYS; ++i) {
+      int rc = copy_range(c, host, i, e0, e1, false);
+      if (rc) return rc;
+    }
+  } else {
+    for (int i : kMutated) {
+      int rc = copy_range(c, host, i, e0, e1, false);
+      if (rc) return rc;
+    }
+  }
+  return CAAR_OK;
+}
+
+int caar_run(CaarContext* c, const CaarParams* p) {
+  if (!c || !p || !p->Dvv) return CAAR_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t n = sizeof(double) * c->dims.np * c->dims.np;
+  if (!c->dvv_valid || std::memcmp(c->dvv_host, p->Dvv, n) != 0) {
+    std::memcpy(c->dvv_host, p->Dvv, n);
+    // dvv_host lives in the context, so the async copy's source outlives the call
+    HIP_TRY(hipMemcpyAsync(c->dvv_dev, c->dvv_host, n, hipMemcpyHostToDevice, c->stream));
+    c->dvv_valid = true;
+  }
+  return caar_launch(&c->dims, &c->dev, c->dvv_dev, p, c->stream);
+}
+
+int caar_sync(CaarContext* c) {
+  if (!c) return CAAR_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return CAAR_OK;
+}
+
+int caar_device_arrays(CaarContext* c, CaarArrays* out) {
+  if (!c || !out) return CAAR_EINVAL;
+  *out = c->dev;
+  return CAAR_OK;
+}
+
+void* caar_stream(CaarContext* c) { return c ? (void*)c->stream : nullptr; }
+
+int caar_state_norms(CaarContext* c, int tl, int e0, int e1, double out[3]) {
+  if (!c || !out || tl < 0 || tl >= c->dims.timelevels || e0 < 0 || e1 > c->dims.num_elems || e0 > e1)
+    return CAAR_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(caar::launch_state_norms(c->dev.elem_state_v, c->dev.elem_state_T, c->dev.elem_state_dp3d,
+                                   c->dims.np, c->dims.nlev, c->dims.timelevels, tl, e0, e1,
+                                   c->norms_dev, c->stream));
+  std::vector<double> h((size_t)3 * (e1 - e0));
+  HIP_TRY(hipMemcpyAsync(h.data(), c->norms_dev, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  // P:388-390: vnorm += pow(compute_norm(...), 2) over elements, then sqrt (P:394-396);
+  // the kernel stores pow(compute_norm, 2) per element and field.
+  double s[3] = {0, 0, 0};
+  for (int e = 0; e < e1 - e0; ++e)
+    for (int f = 0; f < 3; ++f) s[f] += h[(size_t)3 * e + f];
+  for (int f = 0; f < 3; ++f) out[f] = __builtin_sqrt(s[f]);
+  return CAAR_OK;
+}
+
+int caar_time_runs(CaarContext* c, const CaarParams* p, int reps, float* ms_total) {
+  if (!c || !p || reps <= 0 || !ms_total) return CAAR_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  hipEvent_t a, b;
+  HIP_TRY(hipEventCreate(&a));
+  HIP_TRY(hipEventCreate(&b));
+  int rc = caar_run(c, p);  // warm-up (also uploads Dvv)
+  if (rc == CAAR_OK) rc = (int)hipEventRecord(a, c->stream);
+  for (int i = 0; rc == CAAR_OK && i < reps; ++i) rc = caar_run(c, p);
+  if (rc == CAAR_OK) rc = (int)hipEventRecord(b, c->stream);
+  if (rc == CAAR_OK) rc = (int)hipEventSynchronize(b);
+  if (rc == CAAR_OK) rc = (int)hipEventElapsedTime(ms_total, a, b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return rc;
+}
+
+}  // extern "C"

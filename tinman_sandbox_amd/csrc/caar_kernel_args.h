@@ -1,0 +1,41 @@
+// caar_kernel_args.h — kernel argument block shared by the HIP kernels and the ABI layer.
+#ifndef CAAR_KERNEL_ARGS_H
+#define CAAR_KERNEL_ARGS_H
+
+namespace caar {
+
+// Device pointers to element 0 of each array (layouts: include/caar.h) plus the
+// scalars of Homme::Control / Constants / HVCoord (data_structures.hpp:10-76).
+struct KernelArgs {
+  const double* D;
+  const double* Dinv;
+  const double* fcor;
+  const double* spheremp;
+  const double* metdet;
+  const double* rmetdet;
+  double* dp3d;
+  double* v;
+  double* T;
+  const double* phis;
+  const double* Qdp;
+  double* eta_dot_dpdn;
+  double* omega_p;
+  double* phi;
+  const double* pecnd;
+  double* vn0;
+  const double* Dvv;  // np*np, row-major Dvv[i][j]
+  int nets;           // first element of this launch; blockIdx.x counts from it
+  int n0, np1, nm1;
+  int qn0;            // -1: dry
+  int qsize_d, timelevels;
+  double dt2;
+  double rrearth;
+  double eta_ave_w;
+  double rv_over_rd_m1;  // Rwater_vapor/Rgas - 1.0 (P:151), formed on the host in fp64
+  double Rgas;
+  double kappa;
+  double p_top;          // hyai[0]*ps0 (P:84)
+};
+
+}  // namespace caar
+#endif

@@ -1,0 +1,341 @@
+// caar_np4.hip — compute_and_apply_rhs for NP=4 on gfx950 (MI355X), hand-written HIP.
+//
+// Replaces, for one element per workgroup, the whole body of the reference's
+// element loop (compute_and_apply_rhs_test/cxx/pointers_only/compute_and_apply_rhs.cpp:74-258,
+// Fortran fortran/routine_mod.F90:69-191) including the three sphere operators
+// (sphere_operators.cpp:9-129) and the two vertical integrals (P:280-352).
+//
+// Mapping:
+//   * one workgroup = one element; one wavefront = TPW "tiles"; one tile = 4
+//     consecutive levels x 16 GLL points = 64 lanes, lane = sub*16 + a*4 + b.
+//     In the reference layout [lev][a][b] that is 64 consecutive doubles, so every
+//     field access of a wave is one fully coalesced 512 B (scalar) / 1 KiB (v)
+//     segment and each input byte is read exactly once, each output written once.
+//   * the NP x NP Dvv contractions never leave the 16-lane DPP row of their level:
+//     d/da is three row_ror moves, d/db four quad_perm broadcasts — no LDS traffic.
+//   * Dvv and the element's metric terms (D, Dinv, metdet, rmetdet, fcor, spheremp,
+//     phis) are staged once per workgroup in LDS.
+//   * the three vertical integrals (pressure, geopotential, omega) are blocked
+//     scans: in-wave over the 4 levels of a tile, tile totals through LDS, two
+//     workgroup barriers.  Everything else stays in registers from load to store.
+#include <hip/hip_runtime.h>
+
+#include "caar_kernel_args.h"
+
+namespace caar {
+
+// ---------------------------------------------------------------- DPP helpers
+// dpp_ctrl encodings (LLVM AMDGPU): quad_perm = p0|p1<<2|p2<<4|p3<<6,
+// row_ror:n = 0x120+n.  All lanes have a valid source for these controls.
+template <int CTRL>
+__device__ __forceinline__ double dpp(double x) {
+  return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ int dppi(int x) {
+  return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, true);
+}
+
+// Per-lane slices of Dvv for lane (a, b) of a 16-lane row:
+//   ca[r] = Dvv[k_r][a] where k_r is the `a` index of the lane that row_ror:(4r)
+//           delivers to this lane (found by rotating the lane id itself, so the
+//           code does not depend on the rotate direction),
+//   cb[k] = Dvv[k][b].
+struct RowCoef {
+  double ca[4];
+  double cb[4];
+};
+
+// sum_k Dvv[k][a] f[k][b]   (derivative along the first GLL index; S:30,81,121)
+__device__ __forceinline__ double d_da(const RowCoef& c, double f) {
+  double s = c.ca[0] * f;
+  s += c.ca[1] * dpp<0x124>(f);
+  s += c.ca[2] * dpp<0x128>(f);
+  s += c.ca[3] * dpp<0x12C>(f);
+  return s;
+}
+// sum_k Dvv[k][b] f[a][k]   (derivative along the second GLL index; S:31,82,122)
+__device__ __forceinline__ double d_db(const RowCoef& c, double f) {
+  double s = c.cb[0] * dpp<0x00>(f);
+  s += c.cb[1] * dpp<0x55>(f);
+  s += c.cb[2] * dpp<0xAA>(f);
+  s += c.cb[3] * dpp<0xFF>(f);
+  return s;
+}
+
+// Metric 2x2 of this lane's point, row-major m[r][c] -> {m00, m01, m10, m11}.
+struct M22 {
+  double m00, m01, m10, m11;
+};
+
+// gradient_sphere, S:9-48
+__device__ __forceinline__ void gradient_sphere(const RowCoef& c, const M22& Dinv, double rrearth,
+                                                double s, double& g0, double& g1) {
+  const double v1 = d_da(c, s) * rrearth;
+  const double v2 = d_db(c, s) * rrearth;
+  g0 = Dinv.m00 * v1 + Dinv.m10 * v2;
+  g1 = Dinv.m01 * v1 + Dinv.m11 * v2;
+}
+// divergence_sphere, S:50-89
+__device__ __forceinline__ double divergence_sphere(const RowCoef& c, const M22& Dinv, double metdet,
+                                                    double rmetdet, double rrearth, double u, double v) {
+  const double gv0 = metdet * (Dinv.m00 * u + Dinv.m01 * v);
+  const double gv1 = metdet * (Dinv.m10 * u + Dinv.m11 * v);
+  return (d_da(c, gv0) + d_db(c, gv1)) * rmetdet * rrearth;
+}
+// vorticity_sphere, S:91-129
+__device__ __forceinline__ double vorticity_sphere(const RowCoef& c, const M22& D, double rmetdet,
+                                                   double rrearth, double u, double v) {
+  const double vc0 = D.m00 * u + D.m10 * v;
+  const double vc1 = D.m01 * u + D.m11 * v;
+  return (d_da(c, vc1) - d_db(c, vc0)) * rmetdet * rrearth;
+}
+
+// ------------------------------------------------- in-wave scans over the 4 sub-levels
+// Lanes l, l+16, l+32, l+48 hold levels 4t..4t+3 of one GLL point.
+__device__ __forceinline__ double shfl_abs(double x, int src_lane) { return __shfl(x, src_lane, 64); }
+
+// inclusive prefix (towards higher levels) and the matching exclusive value
+__device__ __forceinline__ void scan_down(double x, int lane, int sub, double& incl, double& excl) {
+  double t = shfl_abs(x, lane - 16);
+  if (sub >= 1) x += t;
+  t = shfl_abs(x, lane - 32);
+  if (sub >= 2) x += t;
+  incl = x;
+  t = shfl_abs(x, lane - 16);
+  excl = sub >= 1 ? t : 0.0;
+}
+// inclusive suffix (towards lower level index) and the matching exclusive value
+__device__ __forceinline__ void scan_up(double x, int lane, int sub, double& incl, double& excl) {
+  double t = shfl_abs(x, lane + 16);
+  if (sub <= 2) x += t;
+  t = shfl_abs(x, lane + 32);
+  if (sub <= 1) x += t;
+  incl = x;
+  t = shfl_abs(x, lane + 16);
+  excl = sub <= 2 ? t : 0.0;
+}
+
+// LDS image of the element's metric terms: 13 values per GLL point
+enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, G_D = 80, G_DINV = 144, G_SIZE = 208 };
+
+template <int NLEV, int TPW>
+__global__ __launch_bounds__(NLEV / 4 / TPW * 64) void caar_np4_kernel(const KernelArgs k) {
+  constexpr int PP = 16;               // GLL points per level
+  constexpr int NT = NLEV / 4;         // tiles per element
+  constexpr int WAVES = NT / TPW;
+  constexpr int THREADS = WAVES * 64;
+  constexpr int BLK = NLEV * PP;       // doubles in one scalar field block
+  static_assert(NLEV % 4 == 0 && NT % TPW == 0, "tile decomposition");
+
+  __shared__ double s_dvv[16];
+  __shared__ double s_geo[G_SIZE];
+  __shared__ double s_tot_dp[NT * PP];   // sum of dp over each tile
+  __shared__ double s_tot_div[NT * PP];  // sum of divdp over each tile
+  __shared__ double s_tot_ht[NT * PP];   // sum of Rgas*T_v*dp/p over each tile
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pt = lane & 15;
+  const int sub = lane >> 4;
+  const size_t ie = (size_t)k.nets + blockIdx.x;
+  const size_t tl = (size_t)k.timelevels;
+
+  const double* __restrict__ dp_n0 = k.dp3d + (ie * tl + k.n0) * BLK;
+  const double2* __restrict__ v_n0 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.n0) * BLK * 2);
+  const double* __restrict__ T_n0 = k.T + (ie * tl + k.n0) * BLK;
+  const bool moist = k.qn0 >= 0;
+  const double* __restrict__ Qdp = k.Qdp + ((ie * k.qsize_d + 0) * 2 + (moist ? k.qn0 : 0)) * BLK;
+
+  // ---- phase 0: issue the n0 loads, stage Dvv + metric terms in LDS -----------------
+  double dp[TPW], u[TPW], v[TPW], T[TPW], q[TPW];
+#pragma unroll
+  for (int r = 0; r < TPW; ++r) {
+    const int off = (w * TPW + r) * 64 + lane;
+    dp[r] = dp_n0[off];
+    const double2 uv = v_n0[off];
+    u[r] = uv.x;
+    v[r] = uv.y;
+    T[r] = T_n0[off];
+    q[r] = moist ? Qdp[off] : 0.0;
+  }
+  if (tid < 16) s_dvv[tid] = k.Dvv[tid];
+  for (int idx = tid; idx < G_SIZE; idx += THREADS) {
+    const double* src;
+    if (idx < G_SPHEREMP) src = k.fcor + ie * PP + idx;
+    else if (idx < G_METDET) src = k.spheremp + ie * PP + (idx - G_SPHEREMP);
+    else if (idx < G_RMETDET) src = k.metdet + ie * PP + (idx - G_METDET);
+    else if (idx < G_PHIS) src = k.rmetdet + ie * PP + (idx - G_RMETDET);
+    else if (idx < G_D) src = k.phis + ie * PP + (idx - G_PHIS);
+    else if (idx < G_DINV) src = k.D + ie * PP * 4 + (idx - G_D);
+    else src = k.Dinv + ie * PP * 4 + (idx - G_DINV);
+    s_geo[idx] = *src;
+  }
+  __syncthreads();
+
+  RowCoef c;
+  {
+    const int a = pt >> 2, b = pt & 3;
+    const int s1 = dppi<0x124>(lane), s2 = dppi<0x128>(lane), s3 = dppi<0x12C>(lane);
+    c.ca[0] = s_dvv[a * 4 + a];
+    c.ca[1] = s_dvv[((s1 >> 2) & 3) * 4 + a];
+    c.ca[2] = s_dvv[((s2 >> 2) & 3) * 4 + a];
+    c.ca[3] = s_dvv[((s3 >> 2) & 3) * 4 + a];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) c.cb[kk] = s_dvv[kk * 4 + b];
+  }
+  M22 Dinv;
+  Dinv.m00 = s_geo[G_DINV + pt * 4 + 0];
+  Dinv.m01 = s_geo[G_DINV + pt * 4 + 1];
+  Dinv.m10 = s_geo[G_DINV + pt * 4 + 2];
+  Dinv.m11 = s_geo[G_DINV + pt * 4 + 3];
+  const double metdet = s_geo[G_METDET + pt];
+  const double rmetdet = s_geo[G_RMETDET + pt];
+  const double rrearth = k.rrearth;
+
+  // ---- phase 1: divdp, T_v, in-tile scans of dp and divdp ---------------------------
+  double divdp[TPW], Tv[TPW], ex_dp[TPW], ex_div[TPW];
+#pragma unroll
+  for (int r = 0; r < TPW; ++r) {
+    const int t = w * TPW + r;
+    divdp[r] = divergence_sphere(c, Dinv, metdet, rmetdet, rrearth, u[r] * dp[r], v[r] * dp[r]);  // P:114-121
+    Tv[r] = moist ? T[r] * (1.0 + k.rv_over_rd_m1 * (q[r] / dp[r])) : T[r];                       // P:135,150-151
+    double in_dp, in_div;
+    scan_down(dp[r], lane, sub, in_dp, ex_dp[r]);
+    scan_down(divdp[r], lane, sub, in_div, ex_div[r]);
+    if (sub == 3) {
+      s_tot_dp[t * PP + pt] = in_dp;
+      s_tot_div[t * PP + pt] = in_div;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: p, running divdp sum, hydrostatic increments and their in-tile scan --
+  double p[TPW], rp[TPW], suml[TPW], ht[TPW], ex_ht[TPW];
+  {
+    double base_dp = 0.0, base_div = 0.0;
+    for (int t2 = 0; t2 < w * TPW; ++t2) {  // tiles above this wave's first tile (wave-uniform trip count)
+      base_dp += s_tot_dp[t2 * PP + pt];
+      base_div += s_tot_div[t2 * PP + pt];
+    }
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) {
+      const int t = w * TPW + r;
+      p[r] = (k.p_top + (base_dp + ex_dp[r])) + 0.5 * dp[r];  // P:84,94-96 in closed form
+      suml[r] = base_div + ex_div[r];                          // P:327,339: sum of divdp above
+      rp[r] = 1.0 / p[r];
+      ht[r] = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);              // Rgas*T_v*hkl, hkl = dp/p (P:300-302)
+      double in_ht;
+      scan_up(ht[r], lane, sub, in_ht, ex_ht[r]);
+      if (sub == 0) s_tot_ht[t * PP + pt] = in_ht;
+      base_dp += s_tot_dp[t * PP + pt];
+      base_div += s_tot_div[t * PP + pt];
+    }
+  }
+
+  // issue the loads of the update phase before waiting on the barrier
+  const double2* __restrict__ v_nm1 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.nm1) * BLK * 2);
+  const double* __restrict__ T_nm1 = k.T + (ie * tl + k.nm1) * BLK;
+  const double* __restrict__ dp_nm1 = k.dp3d + (ie * tl + k.nm1) * BLK;
+  double2* __restrict__ v_np1 = reinterpret_cast<double2*>(k.v + (ie * tl + k.np1) * BLK * 2);
+  double* __restrict__ T_np1 = k.T + (ie * tl + k.np1) * BLK;
+  double* __restrict__ dp_np1 = k.dp3d + (ie * tl + k.np1) * BLK;
+  double2* __restrict__ vn0 = reinterpret_cast<double2*>(k.vn0 + ie * BLK * 2);
+  double* __restrict__ omega_p = k.omega_p + ie * BLK;
+  double* __restrict__ phi_out = k.phi + ie * BLK;
+  const double* __restrict__ pecnd = k.pecnd + ie * BLK;
+  double* __restrict__ eta = k.eta_dot_dpdn + ie * (BLK + PP);
+
+  double2 l_vnm1[TPW], l_vn0[TPW];
+  double l_Tnm1[TPW], l_dpnm1[TPW], l_om[TPW], l_pec[TPW], l_eta[TPW];
+#pragma unroll
+  for (int r = 0; r < TPW; ++r) {
+    const int off = (w * TPW + r) * 64 + lane;
+    l_vnm1[r] = v_nm1[off];
+    l_Tnm1[r] = T_nm1[off];
+    l_dpnm1[r] = dp_nm1[off];
+    l_vn0[r] = vn0[off];
+    l_om[r] = omega_p[off];
+    l_pec[r] = pecnd[off];
+    l_eta[r] = eta[off];
+  }
+  double l_eta_last = 0.0;
+  if (tid < PP) l_eta_last = eta[BLK + tid];
+  __syncthreads();
+
+  // ---- phase 3: everything else, level-local -------------------------------------------
+  M22 Dm;
+  Dm.m00 = s_geo[G_D + pt * 4 + 0];
+  Dm.m01 = s_geo[G_D + pt * 4 + 1];
+  Dm.m10 = s_geo[G_D + pt * 4 + 2];
+  Dm.m11 = s_geo[G_D + pt * 4 + 3];
+  const double fcor = s_geo[G_FCOR + pt];
+  const double spheremp = s_geo[G_SPHEREMP + pt];
+  const double phis = s_geo[G_PHIS + pt];
+  const double eta_zero = k.eta_ave_w * 0.0;  // eta_dot_dpdn_tmp == 0 (P:22,172): vertically Lagrangian
+
+  double below = 0.0;  // hydrostatic sum over the tiles below this wave's last tile
+  for (int t2 = NT - 1; t2 > w * TPW + TPW - 1; --t2) below += s_tot_ht[t2 * PP + pt];
+
+#pragma unroll
+  for (int rr = 0; rr < TPW; ++rr) {
+    const int r = TPW - 1 - rr;  // bottom tile of the wave first: `below` accumulates upwards
+    const int t = w * TPW + r;
+    const int off = t * 64 + lane;
+
+    const double phi = (phis + (below + ex_ht[r])) + 0.5 * ht[r];  // P:303,309
+    below += s_tot_ht[t * PP + pt];
+
+    double gp0, gp1;
+    gradient_sphere(c, Dinv, rrearth, p[r], gp0, gp1);            // P:103
+    const double vgrad_p = u[r] * gp0 + v[r] * gp1;               // P:111
+    const double ckk = 0.5 * rp[r], ckl = rp[r];                  // P:333-334 (ckl = 2*ckk)
+    const double om = vgrad_p * rp[r] - ckl * suml[r] - ckk * divdp[r];  // P:325,336,348
+    const double vort = vorticity_sphere(c, Dm, rmetdet, rrearth, u[r], v[r]);  // P:122
+
+    const double Ephi = 0.5 * (u[r] * u[r] + v[r] * v[r]) + phi + l_pec[r];  // P:196
+    double gT0, gT1, gE0, gE1;
+    gradient_sphere(c, Dinv, rrearth, T[r], gT0, gT1);            // P:200
+    const double vgrad_T = u[r] * gT0 + v[r] * gT1;               // P:209
+    gradient_sphere(c, Dinv, rrearth, Ephi, gE0, gE1);            // P:213
+    const double gpterm = Tv[r] * rp[r];                          // P:219
+    const double glnps1 = k.Rgas * gpterm * gp0;                  // P:221
+    const double glnps2 = k.Rgas * gpterm * gp1;                  // P:222
+    const double vtens1 = v[r] * (fcor + vort) - gE0 - glnps1;    // P:227 (v_vadv == 0)
+    const double vtens2 = -u[r] * (fcor + vort) - gE1 - glnps2;   // P:228
+    const double ttens = -vgrad_T + k.kappa * Tv[r] * om;         // P:230 (T_vadv == 0)
+
+    double2 vo;
+    vo.x = spheremp * (l_vnm1[r].x + k.dt2 * vtens1);             // P:251
+    vo.y = spheremp * (l_vnm1[r].y + k.dt2 * vtens2);             // P:252
+    v_np1[off] = vo;
+    T_np1[off] = spheremp * (l_Tnm1[r] + k.dt2 * ttens);          // P:253
+    dp_np1[off] = spheremp * (l_dpnm1[r] - k.dt2 * divdp[r]);     // P:254
+    phi_out[off] = phi;                                           // P:294,303,309
+    omega_p[off] = l_om[r] + k.eta_ave_w * om;                    // P:173
+    double2 vn;
+    vn.x = l_vn0[r].x + k.eta_ave_w * (u[r] * dp[r]);             // P:117
+    vn.y = l_vn0[r].y + k.eta_ave_w * (v[r] * dp[r]);             // P:118
+    vn0[off] = vn;
+    eta[off] = l_eta[r] + eta_zero;                               // P:172
+  }
+  if (tid < PP) eta[BLK + tid] = l_eta_last + eta_zero;           // P:181
+}
+
+// explicit instantiations + launchers --------------------------------------------------
+template <int NLEV, int TPW>
+static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
+  constexpr int THREADS = NLEV / 4 / TPW * 64;
+  hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+  return hipGetLastError();
+}
+
+hipError_t launch_np4_nlev72(const KernelArgs& k, int num_elems, hipStream_t stream) {
+  return launch_np4<72, 3>(k, num_elems, stream);
+}
+hipError_t launch_np4_nlev128(const KernelArgs& k, int num_elems, hipStream_t stream) {
+  return launch_np4<128, 4>(k, num_elems, stream);
+}
+
+}  // namespace caar
