@@ -43,6 +43,20 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """Host threads the CPU baseline may use: the affinity mask, cut to the cgroup CPU
+    quota when there is one and to the GPU box's per-GPU CPU share (16; override with
+    CAAR_BENCH_CORES)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("CAAR_BENCH_CORES", "16"))))
+
+
 def cpu_baseline(np_, nlev, seconds):
     """Times the CPU path on the host cores: oracle/_ref (the reference's own C++,
     kind "reference") when it was built, else oracle/caar_oracle.c (kind "port").
@@ -50,7 +64,7 @@ def cpu_baseline(np_, nlev, seconds):
     hook (data_structures.hpp:58-69)."""
     import numpy as np
     from oracle import pyoracle as po
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     use_ref = po.have_reference(np_, nlev)
     O = po.Oracle()
     per_thread = 256
