@@ -123,6 +123,23 @@ int caar_launch_state_norms(const CaarDims *dims, const CaarArrays *dev, int tl,
 
 /* Name of the kernel caar_launch dispatches for (np, nlev) (for profiles), or NULL. */
 const char *caar_kernel_name(int np, int nlev);
+/* Tuning: each (np, nlev) is compiled in a few launch shapes (tiles per wavefront,
+ * register budget => workgroups per CU).  Variant 0 is the default; all variants
+ * compute the same thing.  Process-wide, not thread-safe against concurrent launches. */
+int caar_num_variants(int np, int nlev);
+int caar_select_variant(int np, int nlev, int variant);
+const char *caar_variant_info(int np, int nlev, int variant);
+
+/* ---- measurement utilities (roofline context; never on the product path) ---------
+ * caar_stream_copy: device copy of n_doubles with 8 or 16 bytes per lane — the measured
+ * HBM ceiling next to the spec peak and the calibration run for the HBM PMC counters.
+ * caar_traffic_skeleton: touches exactly the bytes caar_launch touches (NP=4), same
+ * addressing and access widths, no arithmetic; it OVERWRITES the output arrays with
+ * meaningless values. */
+int caar_stream_copy(double *dst_dev, const double *src_dev, long long n_doubles, int lane_bytes,
+                     void *stream);
+int caar_traffic_skeleton(const CaarDims *dims, const CaarArrays *dev, const CaarParams *params,
+                          void *stream);
 
 /* ---- context API: the library owns the device copies ---------------------------
  * What Homme::compute_and_apply_rhs(TestData&) needs when TestData lives in host

@@ -14,25 +14,39 @@
 #include "caar_kernel_args.h"
 
 namespace caar {
-hipError_t launch_np4_nlev72(const KernelArgs& k, int num_elems, hipStream_t stream);
-hipError_t launch_np4_nlev128(const KernelArgs& k, int num_elems, hipStream_t stream);
+extern KernelVariant kNp4Nlev72[];
+extern int kNp4Nlev72Count;
+extern KernelVariant kNp4Nlev128[];
+extern int kNp4Nlev128Count;
 hipError_t launch_state_norms(const double* v, const double* T, const double* dp, int np, int nlev,
                               int timelevels, int tl, int e0, int e1, double* out3_per_elem,
                               hipStream_t stream);
 
-typedef hipError_t (*launch_fn)(const KernelArgs&, int, hipStream_t);
-struct Variant {
+hipError_t launch_stream_copy(double* dst, const double* src, size_t n_doubles, int lane_bytes,
+                              hipStream_t stream);
+hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int num_elems, hipStream_t stream);
+
+struct Config {
   int np, nlev;
-  launch_fn fn;
-  const char* kernel;
+  const KernelVariant* variants;
+  int count;
+  int selected;
 };
-static const Variant kVariants[] = {
-    {4, 72, launch_np4_nlev72, "caar_np4_kernel<72, 3>"},
-    {4, 128, launch_np4_nlev128, "caar_np4_kernel<128, 4>"},
-};
-static const Variant* find_variant(int np, int nlev) {
-  for (const Variant& v : kVariants)
-    if (v.np == np && v.nlev == nlev) return &v;
+static Config* configs(int* n) {
+  static Config c[] = {
+      {4, 72, kNp4Nlev72, 0, 0},
+      {4, 128, kNp4Nlev128, 0, 0},
+  };
+  c[0].count = kNp4Nlev72Count;
+  c[1].count = kNp4Nlev128Count;
+  *n = (int)(sizeof(c) / sizeof(c[0]));
+  return c;
+}
+static Config* find_config(int np, int nlev) {
+  int n;
+  Config* c = configs(&n);
+  for (int i = 0; i < n; ++i)
+    if (c[i].np == np && c[i].nlev == nlev) return &c[i];
   return nullptr;
 }
 }  // namespace caar
@@ -65,11 +79,29 @@ extern "C" {
 
 int caar_abi_version(void) { return CAAR_ABI_VERSION; }
 
-int caar_supported(int np, int nlev) { return caar::find_variant(np, nlev) != nullptr; }
+int caar_supported(int np, int nlev) { return caar::find_config(np, nlev) != nullptr; }
 
 const char* caar_kernel_name(int np, int nlev) {
-  const caar::Variant* v = caar::find_variant(np, nlev);
-  return v ? v->kernel : nullptr;
+  const caar::Config* c = caar::find_config(np, nlev);
+  return c ? c->variants[c->selected].kernel : nullptr;
+}
+
+int caar_num_variants(int np, int nlev) {
+  const caar::Config* c = caar::find_config(np, nlev);
+  return c ? c->count : 0;
+}
+
+int caar_select_variant(int np, int nlev, int variant) {
+  caar::Config* c = caar::find_config(np, nlev);
+  if (!c) return CAAR_EUNSUPPORTED;
+  if (variant < 0 || variant >= c->count) return CAAR_EINVAL;
+  c->selected = variant;
+  return CAAR_OK;
+}
+
+const char* caar_variant_info(int np, int nlev, int variant) {
+  const caar::Config* c = caar::find_config(np, nlev);
+  return (c && variant >= 0 && variant < c->count) ? c->variants[variant].what : nullptr;
 }
 
 const char* caar_strerror(int rc) {
@@ -114,6 +146,13 @@ static int check_common(const CaarDims* d, const CaarParams* p) {
   return CAAR_OK;
 }
 
+static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const CaarArrays* dev,
+                           const double* dvv_dev, const CaarParams* p);
+static void fill_args(caar::KernelArgs* k, const CaarDims* dims, const CaarArrays* dev,
+                      const double* dvv_dev, const CaarParams* p) {
+  fill_args_impl(*k, dims, dev, dvv_dev, p);
+}
+
 int caar_launch(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev,
                 const CaarParams* p, void* stream) {
   int rc = check_common(dims, p);
@@ -121,12 +160,18 @@ int caar_launch(const CaarDims* dims, const CaarArrays* dev, const double* dvv_d
   if (!dev || !dvv_dev) return CAAR_EINVAL;
   for (int i = 0; i < CAAR_NUM_ARRAYS; ++i)
     if (!*array_slot(dev, i)) return CAAR_EINVAL;
-  const caar::Variant* var = caar::find_variant(dims->np, dims->nlev);
-  if (!var) return CAAR_EUNSUPPORTED;
+  const caar::Config* cfg = caar::find_config(dims->np, dims->nlev);
+  if (!cfg) return CAAR_EUNSUPPORTED;
   const int n = p->nete - p->nets;
   if (n == 0) return CAAR_OK;
 
   caar::KernelArgs k;
+  fill_args(&k, dims, dev, dvv_dev, p);
+  return (int)cfg->variants[cfg->selected].launch(k, n, (hipStream_t)stream);
+}
+
+static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const CaarArrays* dev,
+                           const double* dvv_dev, const CaarParams* p) {
   k.D = dev->elem_D;
   k.Dinv = dev->elem_Dinv;
   k.fcor = dev->elem_fcor;
@@ -158,7 +203,25 @@ int caar_launch(const CaarDims* dims, const CaarArrays* dev, const double* dvv_d
   k.Rgas = p->Rgas;
   k.kappa = p->kappa;
   k.p_top = p->hyai0 * p->ps0;  // P:84
-  return (int)var->fn(k, n, (hipStream_t)stream);
+}
+
+/* Measurement utilities (roofline context; not used by the product path). */
+int caar_stream_copy(double* dst_dev, const double* src_dev, long long n_doubles, int lane_bytes,
+                     void* stream) {
+  if (!dst_dev || !src_dev || n_doubles <= 0 || (lane_bytes != 8 && lane_bytes != 16)) return CAAR_EINVAL;
+  return (int)caar::launch_stream_copy(dst_dev, src_dev, (size_t)n_doubles, lane_bytes, (hipStream_t)stream);
+}
+
+int caar_traffic_skeleton(const CaarDims* dims, const CaarArrays* dev, const CaarParams* p, void* stream) {
+  int rc = check_common(dims, p);
+  if (rc) return rc;
+  if (!dev || dims->np != 4) return CAAR_EUNSUPPORTED;
+  for (int i = 0; i < CAAR_NUM_ARRAYS; ++i)
+    if (!*array_slot(dev, i)) return CAAR_EINVAL;
+  if (p->nete == p->nets) return CAAR_OK;
+  caar::KernelArgs k;
+  fill_args_impl(k, dims, dev, nullptr, p);
+  return (int)caar::launch_traffic_skeleton(k, dims->nlev, p->nete - p->nets, (hipStream_t)stream);
 }
 
 int caar_launch_state_norms(const CaarDims* d, const CaarArrays* dev, int tl, int e0, int e1,
@@ -173,7 +236,7 @@ int caar_launch_state_norms(const CaarDims* d, const CaarArrays* dev, int tl, in
 // ------------------------------------------------------------------ context API
 int caar_create(CaarContext** out, const CaarDims* dims, int device) {
   if (!out || !dims || dims->num_elems <= 0) return CAAR_EINVAL;
-  if (!caar::find_variant(dims->np, dims->nlev)) return CAAR_EUNSUPPORTED;
+  if (!caar::find_config(dims->np, dims->nlev)) return CAAR_EUNSUPPORTED;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CAAR_ENODEVICE;
   if (device < 0 || device >= ndev) return CAAR_EINVAL;

@@ -2,6 +2,8 @@
 #ifndef CAAR_KERNEL_ARGS_H
 #define CAAR_KERNEL_ARGS_H
 
+#include <hip/hip_runtime.h>
+
 namespace caar {
 
 // Device pointers to element 0 of each array (layouts: include/caar.h) plus the
@@ -35,6 +37,13 @@ struct KernelArgs {
   double Rgas;
   double kappa;
   double p_top;          // hyai[0]*ps0 (P:84)
+};
+
+// One compiled kernel configuration for a given (np, nlev).
+struct KernelVariant {
+  const char* kernel;  // demangled kernel name as rocprofv3 prints it
+  const char* what;
+  hipError_t (*launch)(const KernelArgs&, int num_elems, hipStream_t stream);
 };
 
 }  // namespace caar

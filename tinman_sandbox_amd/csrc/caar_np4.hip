@@ -119,8 +119,8 @@ __device__ __forceinline__ void scan_up(double x, int lane, int sub, double& inc
 // LDS image of the element's metric terms: 13 values per GLL point
 enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, G_D = 80, G_DINV = 144, G_SIZE = 208 };
 
-template <int NLEV, int TPW>
-__global__ __launch_bounds__(NLEV / 4 / TPW * 64) void caar_np4_kernel(const KernelArgs k) {
+template <int NLEV, int TPW, int MINW, bool SCHED_FENCE>
+__global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
   constexpr int PP = 16;               // GLL points per level
   constexpr int NT = NLEV / 4;         // tiles per element
   constexpr int WAVES = NT / TPW;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64) void caar_np4_kernel(const Ker
   __syncthreads();
 
   // ---- phase 2: p, running divdp sum, hydrostatic increments and their in-tile scan --
-  double p[TPW], rp[TPW], suml[TPW], ht[TPW], ex_ht[TPW];
+  double p[TPW], rp[TPW], suml[TPW], ex_ht[TPW];
   {
     double base_dp = 0.0, base_div = 0.0;
     for (int t2 = 0; t2 < w * TPW; ++t2) {  // tiles above this wave's first tile (wave-uniform trip count)
@@ -225,16 +225,16 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64) void caar_np4_kernel(const Ker
       p[r] = (k.p_top + (base_dp + ex_dp[r])) + 0.5 * dp[r];  // P:84,94-96 in closed form
       suml[r] = base_div + ex_div[r];                          // P:327,339: sum of divdp above
       rp[r] = 1.0 / p[r];
-      ht[r] = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);              // Rgas*T_v*hkl, hkl = dp/p (P:300-302)
+      const double ht = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);    // Rgas*T_v*hkl, hkl = dp/p (P:300-302)
       double in_ht;
-      scan_up(ht[r], lane, sub, in_ht, ex_ht[r]);
+      scan_up(ht, lane, sub, in_ht, ex_ht[r]);
       if (sub == 0) s_tot_ht[t * PP + pt] = in_ht;
       base_dp += s_tot_dp[t * PP + pt];
       base_div += s_tot_div[t * PP + pt];
     }
   }
 
-  // issue the loads of the update phase before waiting on the barrier
+  // pointers of the update phase
   const double2* __restrict__ v_nm1 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.nm1) * BLK * 2);
   const double* __restrict__ T_nm1 = k.T + (ie * tl + k.nm1) * BLK;
   const double* __restrict__ dp_nm1 = k.dp3d + (ie * tl + k.nm1) * BLK;
@@ -247,19 +247,25 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64) void caar_np4_kernel(const Ker
   const double* __restrict__ pecnd = k.pecnd + ie * BLK;
   double* __restrict__ eta = k.eta_dot_dpdn + ie * (BLK + PP);
 
-  double2 l_vnm1[TPW], l_vn0[TPW];
-  double l_Tnm1[TPW], l_dpnm1[TPW], l_om[TPW], l_pec[TPW], l_eta[TPW];
-#pragma unroll
-  for (int r = 0; r < TPW; ++r) {
-    const int off = (w * TPW + r) * 64 + lane;
-    l_vnm1[r] = v_nm1[off];
-    l_Tnm1[r] = T_nm1[off];
-    l_dpnm1[r] = dp_nm1[off];
-    l_vn0[r] = vn0[off];
-    l_om[r] = omega_p[off];
-    l_pec[r] = pecnd[off];
-    l_eta[r] = eta[off];
-  }
+  // Update-phase inputs of one tile; loaded one tile ahead of their use so that only
+  // two tiles' worth of them are ever live (register budget: 2 workgroups per CU).
+  struct TileIn {
+    double2 vnm1, vn0;
+    double Tnm1, dpnm1, om, pec, eta;
+  };
+  auto load_tile = [&](int t) {
+    const int off = t * 64 + lane;
+    TileIn x;
+    x.vnm1 = v_nm1[off];
+    x.Tnm1 = T_nm1[off];
+    x.dpnm1 = dp_nm1[off];
+    x.vn0 = vn0[off];
+    x.om = omega_p[off];
+    x.pec = pecnd[off];
+    x.eta = eta[off];
+    return x;
+  };
+  TileIn cur = load_tile(w * TPW + TPW - 1);  // in flight across the barrier
   double l_eta_last = 0.0;
   if (tid < PP) l_eta_last = eta[BLK + tid];
   __syncthreads();
@@ -283,8 +289,11 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64) void caar_np4_kernel(const Ker
     const int r = TPW - 1 - rr;  // bottom tile of the wave first: `below` accumulates upwards
     const int t = w * TPW + r;
     const int off = t * 64 + lane;
+    TileIn nxt = cur;
+    if (r > 0) nxt = load_tile(t - 1);
 
-    const double phi = (phis + (below + ex_ht[r])) + 0.5 * ht[r];  // P:303,309
+    const double ht = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);         // same expression as in phase 2
+    const double phi = (phis + (below + ex_ht[r])) + 0.5 * ht;    // P:303,309
     below += s_tot_ht[t * PP + pt];
 
     double gp0, gp1;
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64) void caar_np4_kernel(const Ker
     const double om = vgrad_p * rp[r] - ckl * suml[r] - ckk * divdp[r];  // P:325,336,348
     const double vort = vorticity_sphere(c, Dm, rmetdet, rrearth, u[r], v[r]);  // P:122
 
-    const double Ephi = 0.5 * (u[r] * u[r] + v[r] * v[r]) + phi + l_pec[r];  // P:196
+    const double Ephi = 0.5 * (u[r] * u[r] + v[r] * v[r]) + phi + cur.pec;  // P:196
     double gT0, gT1, gE0, gE1;
     gradient_sphere(c, Dinv, rrearth, T[r], gT0, gT1);            // P:200
     const double vgrad_T = u[r] * gT0 + v[r] * gT1;               // P:209
@@ -307,35 +316,51 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64) void caar_np4_kernel(const Ker
     const double ttens = -vgrad_T + k.kappa * Tv[r] * om;         // P:230 (T_vadv == 0)
 
     double2 vo;
-    vo.x = spheremp * (l_vnm1[r].x + k.dt2 * vtens1);             // P:251
-    vo.y = spheremp * (l_vnm1[r].y + k.dt2 * vtens2);             // P:252
+    vo.x = spheremp * (cur.vnm1.x + k.dt2 * vtens1);              // P:251
+    vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);              // P:252
     v_np1[off] = vo;
-    T_np1[off] = spheremp * (l_Tnm1[r] + k.dt2 * ttens);          // P:253
-    dp_np1[off] = spheremp * (l_dpnm1[r] - k.dt2 * divdp[r]);     // P:254
+    T_np1[off] = spheremp * (cur.Tnm1 + k.dt2 * ttens);           // P:253
+    dp_np1[off] = spheremp * (cur.dpnm1 - k.dt2 * divdp[r]);      // P:254
     phi_out[off] = phi;                                           // P:294,303,309
-    omega_p[off] = l_om[r] + k.eta_ave_w * om;                    // P:173
+    omega_p[off] = cur.om + k.eta_ave_w * om;                     // P:173
     double2 vn;
-    vn.x = l_vn0[r].x + k.eta_ave_w * (u[r] * dp[r]);             // P:117
-    vn.y = l_vn0[r].y + k.eta_ave_w * (v[r] * dp[r]);             // P:118
+    vn.x = cur.vn0.x + k.eta_ave_w * (u[r] * dp[r]);              // P:117
+    vn.y = cur.vn0.y + k.eta_ave_w * (v[r] * dp[r]);              // P:118
     vn0[off] = vn;
-    eta[off] = l_eta[r] + eta_zero;                               // P:172
+    eta[off] = cur.eta + eta_zero;                                // P:172
+    cur = nxt;
+    if (SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
   }
   if (tid < PP) eta[BLK + tid] = l_eta_last + eta_zero;           // P:181
 }
 
 // explicit instantiations + launchers --------------------------------------------------
-template <int NLEV, int TPW>
+template <int NLEV, int TPW, int MINW, bool SCHED_FENCE>
 static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = NLEV / 4 / TPW * 64;
-  hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+  hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, SCHED_FENCE>), dim3(num_elems), dim3(THREADS), 0, stream, k);
   return hipGetLastError();
 }
 
-hipError_t launch_np4_nlev72(const KernelArgs& k, int num_elems, hipStream_t stream) {
-  return launch_np4<72, 3>(k, num_elems, stream);
-}
-hipError_t launch_np4_nlev128(const KernelArgs& k, int num_elems, hipStream_t stream) {
-  return launch_np4<128, 4>(k, num_elems, stream);
-}
+// Tuning variants (caar_select_variant): TPW = tiles per wave, MINW = waves per SIMD the
+// register allocator must leave room for (=> workgroups per CU).  Index 0 is the default.
+// (non-const on purpose: const globals are also emitted for the device, where the host
+// launchers they point to do not exist)
+KernelVariant kNp4Nlev72[] = {
+    {"caar_np4_kernel<72, 2, 1, false>", "9 waves x 2 tiles, 1 workgroup/CU", launch_np4<72, 2, 1, false>},
+    {"caar_np4_kernel<72, 3, 3, false>", "6 waves x 3 tiles, <=168 VGPR: 2 workgroups/CU", launch_np4<72, 3, 3, false>},
+    {"caar_np4_kernel<72, 3, 1, false>", "6 waves x 3 tiles, unconstrained registers: 1 workgroup/CU", launch_np4<72, 3, 1, false>},
+    {"caar_np4_kernel<72, 6, 1, false>", "3 waves x 6 tiles", launch_np4<72, 6, 1, false>},
+    {"caar_np4_kernel<72, 3, 3, true>", "6 waves x 3 tiles, tiles fenced in the scheduler", launch_np4<72, 3, 3, true>},
+};
+int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
+
+KernelVariant kNp4Nlev128[] = {
+    {"caar_np4_kernel<128, 4, 2, false>", "8 waves x 4 tiles", launch_np4<128, 4, 2, false>},
+    {"caar_np4_kernel<128, 2, 1, false>", "16 waves x 2 tiles", launch_np4<128, 2, 1, false>},
+    {"caar_np4_kernel<128, 8, 1, false>", "4 waves x 8 tiles", launch_np4<128, 8, 1, false>},
+    {"caar_np4_kernel<128, 4, 3, false>", "8 waves x 4 tiles, <=168 VGPR", launch_np4<128, 4, 3, false>},
+};
+int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 
 }  // namespace caar
