@@ -18,6 +18,8 @@ extern KernelVariant kNp4Nlev72[];
 extern int kNp4Nlev72Count;
 extern KernelVariant kNp4Nlev128[];
 extern int kNp4Nlev128Count;
+extern KernelVariant kNp8Nlev72[];
+extern int kNp8Nlev72Count;
 hipError_t launch_state_norms(const double* v, const double* T, const double* dp, int np, int nlev,
                               int timelevels, int tl, int e0, int e1, double* out3_per_elem,
                               hipStream_t stream);
@@ -36,9 +38,11 @@ static Config* configs(int* n) {
   static Config c[] = {
       {4, 72, kNp4Nlev72, 0, 0},
       {4, 128, kNp4Nlev128, 0, 0},
+      {8, 72, kNp8Nlev72, 0, 0},
   };
   c[0].count = kNp4Nlev72Count;
   c[1].count = kNp4Nlev128Count;
+  c[2].count = kNp8Nlev72Count;
   *n = (int)(sizeof(c) / sizeof(c[0]));
   return c;
 }

@@ -39,6 +39,20 @@ struct KernelArgs {
   double p_top;          // hyai[0]*ps0 (P:84)
 };
 
+// 1/x for a normal, non-zero fp64 x: v_rcp_f64 seed + two Newton steps (5 instructions,
+// <= 1 ulp), instead of the IEEE division sequence (v_div_scale/fmas/fixup, ~12
+// instructions and twice the live registers).  The reference divides by p and dp3d
+// (P:150,219,291,323); both are positive pressures, so no scaling or fix-up is needed.
+// Error budget: DESIGN.md "Numerics".
+__device__ __forceinline__ double recip(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+
 // One compiled kernel configuration for a given (np, nlev).
 struct KernelVariant {
   const char* kernel;  // demangled kernel name as rocprofv3 prints it

@@ -119,7 +119,7 @@ __device__ __forceinline__ void scan_up(double x, int lane, int sub, double& inc
 // LDS image of the element's metric terms: 13 values per GLL point
 enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, G_D = 80, G_DINV = 144, G_SIZE = 208 };
 
-template <int NLEV, int TPW, int MINW, bool SCHED_FENCE>
+template <int NLEV, int TPW, int MINW, bool MOIST>
 __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
   constexpr int PP = 16;               // GLL points per level
   constexpr int NT = NLEV / 4;         // tiles per element
@@ -141,24 +141,28 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
   const int sub = lane >> 4;
   const size_t ie = (size_t)k.nets + blockIdx.x;
   const size_t tl = (size_t)k.timelevels;
+  // Addressing: every field pointer below is wave-uniform (element, time level and this
+  // wave's first tile folded in: an SGPR pair) and is indexed by `r * 64 + ulane` with r
+  // a compile-time tile number and ulane an UNSIGNED lane id, so each access is one
+  // global_load/store with scalar base, one shared 32-bit lane offset and an immediate.
+  const unsigned ulane = lane;
+  const size_t wbase = (size_t)w * (TPW * 64);  // first point of this wave's tiles inside a field block
 
-  const double* __restrict__ dp_n0 = k.dp3d + (ie * tl + k.n0) * BLK;
-  const double2* __restrict__ v_n0 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.n0) * BLK * 2);
-  const double* __restrict__ T_n0 = k.T + (ie * tl + k.n0) * BLK;
-  const bool moist = k.qn0 >= 0;
-  const double* __restrict__ Qdp = k.Qdp + ((ie * k.qsize_d + 0) * 2 + (moist ? k.qn0 : 0)) * BLK;
+  const double* __restrict__ dp_n0 = k.dp3d + (ie * tl + k.n0) * BLK + wbase;
+  const double2* __restrict__ v_n0 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.n0) * BLK * 2) + wbase;
+  const double* __restrict__ T_n0 = k.T + (ie * tl + k.n0) * BLK + wbase;
+  const double* __restrict__ Qdp = k.Qdp + ((ie * k.qsize_d + 0) * 2 + (MOIST ? k.qn0 : 0)) * BLK + wbase;
 
   // ---- phase 0: issue the n0 loads, stage Dvv + metric terms in LDS -----------------
   double dp[TPW], u[TPW], v[TPW], T[TPW], q[TPW];
 #pragma unroll
   for (int r = 0; r < TPW; ++r) {
-    const int off = (w * TPW + r) * 64 + lane;
-    dp[r] = dp_n0[off];
-    const double2 uv = v_n0[off];
+    dp[r] = dp_n0[r * 64 + ulane];
+    const double2 uv = v_n0[r * 64 + ulane];
     u[r] = uv.x;
     v[r] = uv.y;
-    T[r] = T_n0[off];
-    q[r] = moist ? Qdp[off] : 0.0;
+    T[r] = T_n0[r * 64 + ulane];
+    q[r] = MOIST ? Qdp[r * 64 + ulane] : 0.0;
   }
   if (tid < 16) s_dvv[tid] = k.Dvv[tid];
   for (int idx = tid; idx < G_SIZE; idx += THREADS) {
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
   for (int r = 0; r < TPW; ++r) {
     const int t = w * TPW + r;
     divdp[r] = divergence_sphere(c, Dinv, metdet, rmetdet, rrearth, u[r] * dp[r], v[r] * dp[r]);  // P:114-121
-    Tv[r] = moist ? T[r] * (1.0 + k.rv_over_rd_m1 * (q[r] / dp[r])) : T[r];                       // P:135,150-151
+    Tv[r] = MOIST ? T[r] * (1.0 + k.rv_over_rd_m1 * (q[r] * recip(dp[r]))) : T[r];                       // P:135,150-151
     double in_dp, in_div;
     scan_down(dp[r], lane, sub, in_dp, ex_dp[r]);
     scan_down(divdp[r], lane, sub, in_div, ex_div[r]);
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
       const int t = w * TPW + r;
       p[r] = (k.p_top + (base_dp + ex_dp[r])) + 0.5 * dp[r];  // P:84,94-96 in closed form
       suml[r] = base_div + ex_div[r];                          // P:327,339: sum of divdp above
-      rp[r] = 1.0 / p[r];
+      rp[r] = recip(p[r]);
       const double ht = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);    // Rgas*T_v*hkl, hkl = dp/p (P:300-302)
       double in_ht;
       scan_up(ht, lane, sub, in_ht, ex_ht[r]);
@@ -235,17 +239,18 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
   }
 
   // pointers of the update phase
-  const double2* __restrict__ v_nm1 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.nm1) * BLK * 2);
-  const double* __restrict__ T_nm1 = k.T + (ie * tl + k.nm1) * BLK;
-  const double* __restrict__ dp_nm1 = k.dp3d + (ie * tl + k.nm1) * BLK;
-  double2* __restrict__ v_np1 = reinterpret_cast<double2*>(k.v + (ie * tl + k.np1) * BLK * 2);
-  double* __restrict__ T_np1 = k.T + (ie * tl + k.np1) * BLK;
-  double* __restrict__ dp_np1 = k.dp3d + (ie * tl + k.np1) * BLK;
-  double2* __restrict__ vn0 = reinterpret_cast<double2*>(k.vn0 + ie * BLK * 2);
-  double* __restrict__ omega_p = k.omega_p + ie * BLK;
-  double* __restrict__ phi_out = k.phi + ie * BLK;
-  const double* __restrict__ pecnd = k.pecnd + ie * BLK;
-  double* __restrict__ eta = k.eta_dot_dpdn + ie * (BLK + PP);
+  const double2* __restrict__ v_nm1 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.nm1) * BLK * 2) + wbase;
+  const double* __restrict__ T_nm1 = k.T + (ie * tl + k.nm1) * BLK + wbase;
+  const double* __restrict__ dp_nm1 = k.dp3d + (ie * tl + k.nm1) * BLK + wbase;
+  double2* __restrict__ v_np1 = reinterpret_cast<double2*>(k.v + (ie * tl + k.np1) * BLK * 2) + wbase;
+  double* __restrict__ T_np1 = k.T + (ie * tl + k.np1) * BLK + wbase;
+  double* __restrict__ dp_np1 = k.dp3d + (ie * tl + k.np1) * BLK + wbase;
+  double2* __restrict__ vn0 = reinterpret_cast<double2*>(k.vn0 + ie * BLK * 2) + wbase;
+  double* __restrict__ omega_p = k.omega_p + ie * BLK + wbase;
+  double* __restrict__ phi_out = k.phi + ie * BLK + wbase;
+  const double* __restrict__ pecnd = k.pecnd + ie * BLK + wbase;
+  double* __restrict__ eta = k.eta_dot_dpdn + ie * (BLK + PP) + wbase;
+  double* __restrict__ eta_last = k.eta_dot_dpdn + ie * (BLK + PP) + BLK;
 
   // Update-phase inputs of one tile; loaded one tile ahead of their use so that only
   // two tiles' worth of them are ever live (register budget: 2 workgroups per CU).
@@ -253,8 +258,8 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
     double2 vnm1, vn0;
     double Tnm1, dpnm1, om, pec, eta;
   };
-  auto load_tile = [&](int t) {
-    const int off = t * 64 + lane;
+  auto load_tile = [&](int r) {
+    const unsigned off = r * 64 + ulane;
     TileIn x;
     x.vnm1 = v_nm1[off];
     x.Tnm1 = T_nm1[off];
@@ -265,9 +270,9 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
     x.eta = eta[off];
     return x;
   };
-  TileIn cur = load_tile(w * TPW + TPW - 1);  // in flight across the barrier
+  TileIn cur = load_tile(TPW - 1);  // in flight across the barrier
   double l_eta_last = 0.0;
-  if (tid < PP) l_eta_last = eta[BLK + tid];
+  if (tid < PP) l_eta_last = eta_last[ulane];
   __syncthreads();
 
   // ---- phase 3: everything else, level-local -------------------------------------------
@@ -288,9 +293,9 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
   for (int rr = 0; rr < TPW; ++rr) {
     const int r = TPW - 1 - rr;  // bottom tile of the wave first: `below` accumulates upwards
     const int t = w * TPW + r;
-    const int off = t * 64 + lane;
+    const unsigned off = r * 64 + ulane;
     TileIn nxt = cur;
-    if (r > 0) nxt = load_tile(t - 1);
+    if (r > 0) nxt = load_tile(r - 1);
 
     const double ht = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);         // same expression as in phase 2
     const double phi = (phis + (below + ex_ht[r])) + 0.5 * ht;    // P:303,309
@@ -329,16 +334,18 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
     vn0[off] = vn;
     eta[off] = cur.eta + eta_zero;                                // P:172
     cur = nxt;
-    if (SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
   }
-  if (tid < PP) eta[BLK + tid] = l_eta_last + eta_zero;           // P:181
+  if (tid < PP) eta_last[ulane] = l_eta_last + eta_zero;          // P:181
 }
 
 // explicit instantiations + launchers --------------------------------------------------
-template <int NLEV, int TPW, int MINW, bool SCHED_FENCE>
+template <int NLEV, int TPW, int MINW>
 static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = NLEV / 4 / TPW * 64;
-  hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, SCHED_FENCE>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+  if (k.qn0 >= 0)
+    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+  else  // dry branch (P:128-139): the Qdp block is never touched
+    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false>), dim3(num_elems), dim3(THREADS), 0, stream, k);
   return hipGetLastError();
 }
 
@@ -347,19 +354,19 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
-    {"caar_np4_kernel<72, 2, 1, false>", "9 waves x 2 tiles, 1 workgroup/CU", launch_np4<72, 2, 1, false>},
-    {"caar_np4_kernel<72, 3, 3, false>", "6 waves x 3 tiles, <=168 VGPR: 2 workgroups/CU", launch_np4<72, 3, 3, false>},
-    {"caar_np4_kernel<72, 3, 1, false>", "6 waves x 3 tiles, unconstrained registers: 1 workgroup/CU", launch_np4<72, 3, 1, false>},
-    {"caar_np4_kernel<72, 6, 1, false>", "3 waves x 6 tiles", launch_np4<72, 6, 1, false>},
-    {"caar_np4_kernel<72, 3, 3, true>", "6 waves x 3 tiles, tiles fenced in the scheduler", launch_np4<72, 3, 3, true>},
+    {"caar_np4_kernel<72, 2, 1, true>", "9 waves x 2 tiles", launch_np4<72, 2, 1>},
+    {"caar_np4_kernel<72, 2, 4, true>", "9 waves x 2 tiles, <=128 VGPR", launch_np4<72, 2, 4>},
+    {"caar_np4_kernel<72, 3, 3, true>", "6 waves x 3 tiles, <=168 VGPR: 2 workgroups/CU", launch_np4<72, 3, 3>},
+    {"caar_np4_kernel<72, 3, 1, true>", "6 waves x 3 tiles", launch_np4<72, 3, 1>},
+    {"caar_np4_kernel<72, 6, 1, true>", "3 waves x 6 tiles", launch_np4<72, 6, 1>},
 };
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
-    {"caar_np4_kernel<128, 4, 2, false>", "8 waves x 4 tiles", launch_np4<128, 4, 2, false>},
-    {"caar_np4_kernel<128, 2, 1, false>", "16 waves x 2 tiles", launch_np4<128, 2, 1, false>},
-    {"caar_np4_kernel<128, 8, 1, false>", "4 waves x 8 tiles", launch_np4<128, 8, 1, false>},
-    {"caar_np4_kernel<128, 4, 3, false>", "8 waves x 4 tiles, <=168 VGPR", launch_np4<128, 4, 3, false>},
+    {"caar_np4_kernel<128, 4, 2, true>", "8 waves x 4 tiles", launch_np4<128, 4, 2>},
+    {"caar_np4_kernel<128, 2, 1, true>", "16 waves x 2 tiles", launch_np4<128, 2, 1>},
+    {"caar_np4_kernel<128, 8, 1, true>", "4 waves x 8 tiles", launch_np4<128, 8, 1>},
+    {"caar_np4_kernel<128, 4, 3, true>", "8 waves x 4 tiles, <=168 VGPR", launch_np4<128, 4, 3>},
 };
 int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 

@@ -1,0 +1,361 @@
+// caar_np8.hip — compute_and_apply_rhs for NP=8 on gfx950 (MI355X), hand-written HIP.
+//
+// Same algorithm and reference citations as caar_np4.hip (P = cxx/pointers_only/
+// compute_and_apply_rhs.cpp, S = sphere_operators.cpp); different mapping because one
+// level of an NP=8 element is exactly one wavefront:
+//   * one workgroup = one element; lane = GLL point a*8+b; a wave owns TPW consecutive
+//     levels and walks them in registers, so the three vertical integrals are plain
+//     running sums inside a wave (the reference's own summation order within the
+//     chunk) plus one wave total per integral exchanged through LDS (two barriers).
+//   * every field access of a wave is one contiguous 512 B (scalar) / 1 KiB (v) row of
+//     the reference layout [lev][a][b]: each byte read once, written once.
+//   * the 8x8 Dvv contractions go through a wave-private 512 B LDS tile: the field is
+//     written once and each lane reads its row (4 x ds_read_b128) or column
+//     (8 x ds_read_b64); Dvv is staged transposed in LDS so that both coefficient
+//     vectors are contiguous.  fp64 MFMA was not used: on MI355X v_mfma_f64 runs at
+//     the vector fp64 rate and an 8x8 operand fills half of its 16x16 tile.
+//   * an NP=8 element does not fit the register file the way an NP=4 one does (7 live
+//     values x 64 points x 72 levels = 258 KB): between the phases dp, u, v, T of every
+//     level are read through a two-deep prefetch ring, dp, u, v are parked in LDS
+//     (3 x 36 KB, each lane re-reads only what it wrote) and only {T, T_v, divdp}
+//     stay in registers; p, 1/p and the divdp prefix are re-formed
+//     in the last phase from the running sums.
+#include <hip/hip_runtime.h>
+
+#include "caar_kernel_args.h"
+
+namespace caar {
+
+namespace np8 {
+
+constexpr int NP = 8, PP = 64;
+enum { G_FCOR = 0, G_SPHEREMP = 64, G_METDET = 128, G_RMETDET = 192, G_PHIS = 256, G_D = 320, G_DINV = 576, G_SIZE = 832 };
+
+// wave-private LDS is written and read by different lanes of the same wave: LDS
+// instructions of one wave execute in order, the fence only pins the compiler.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct Ctx {
+  double ca[NP];  // ca[k] = Dvv[k][a]
+  double cb[NP];  // cb[k] = Dvv[k][b]
+  double* tile;   // LDS, this wave's 64-double tile
+  int a, b;
+};
+
+// sum_k Dvv[k][a] f[k][b] and sum_k Dvv[k][b] f[a][k] of the field currently in c.tile
+__device__ __forceinline__ double d_da_tile(const Ctx& c) {
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) s += c.ca[k] * c.tile[k * NP + c.b];
+  return s;
+}
+__device__ __forceinline__ double d_db_tile(const Ctx& c) {
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) s += c.cb[k] * c.tile[c.a * NP + k];
+  return s;
+}
+__device__ __forceinline__ void put_tile(const Ctx& c, int lane, double f) {
+  wave_lds_fence();  // earlier reads of the tile are done
+  c.tile[lane] = f;
+  wave_lds_fence();
+}
+
+struct M22 {
+  double m00, m01, m10, m11;
+};
+__device__ __forceinline__ M22 load_m22(const double* g, int pt) {
+  M22 m;
+  m.m00 = g[pt * 4 + 0];
+  m.m01 = g[pt * 4 + 1];
+  m.m10 = g[pt * 4 + 2];
+  m.m11 = g[pt * 4 + 3];
+  return m;
+}
+
+// gradient_sphere, S:9-48
+__device__ __forceinline__ void gradient_sphere(const Ctx& c, int lane, const M22& Dinv, double rrearth,
+                                                double s, double& g0, double& g1) {
+  put_tile(c, lane, s);
+  const double v1 = d_da_tile(c) * rrearth;
+  const double v2 = d_db_tile(c) * rrearth;
+  g0 = Dinv.m00 * v1 + Dinv.m10 * v2;
+  g1 = Dinv.m01 * v1 + Dinv.m11 * v2;
+}
+// divergence_sphere, S:50-89
+__device__ __forceinline__ double divergence_sphere(const Ctx& c, int lane, const M22& Dinv, double metdet,
+                                                    double rmetdet, double rrearth, double u, double v) {
+  const double gv0 = metdet * (Dinv.m00 * u + Dinv.m01 * v);
+  const double gv1 = metdet * (Dinv.m10 * u + Dinv.m11 * v);
+  put_tile(c, lane, gv0);
+  const double dudx = d_da_tile(c);
+  put_tile(c, lane, gv1);
+  const double dvdy = d_db_tile(c);
+  return (dudx + dvdy) * rmetdet * rrearth;
+}
+// vorticity_sphere, S:91-129
+__device__ __forceinline__ double vorticity_sphere(const Ctx& c, int lane, const M22& D, double rmetdet,
+                                                   double rrearth, double u, double v) {
+  const double vc0 = D.m00 * u + D.m10 * v;
+  const double vc1 = D.m01 * u + D.m11 * v;
+  put_tile(c, lane, vc1);
+  const double dvdx = d_da_tile(c);
+  put_tile(c, lane, vc0);
+  const double dudy = d_db_tile(c);
+  return (dvdx - dudy) * rmetdet * rrearth;
+}
+
+}  // namespace np8
+
+template <int NLEV, int TPW, int MINW, bool MOIST>
+__global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const KernelArgs k) {
+  using namespace np8;
+  constexpr int WAVES = NLEV / TPW;
+  constexpr int THREADS = WAVES * 64;
+  constexpr int BLK = NLEV * PP;
+  static_assert(NLEV % TPW == 0 && THREADS <= 1024, "level decomposition");
+
+  __shared__ __attribute__((aligned(16))) double s_dvvT[64];
+  __shared__ __attribute__((aligned(16))) double s_geo[G_SIZE];
+  __shared__ __attribute__((aligned(16))) double s_tile[WAVES * 64];
+  __shared__ double s_park[3 * BLK];        // dp, u, v of every level, [field][lev][pt]
+  __shared__ double s_tot_dp[WAVES * PP];   // per wave: sum of dp over its levels
+  __shared__ double s_tot_div[WAVES * PP];  // ... of divdp
+  __shared__ double s_tot_ht[WAVES * PP];   // ... of Rgas*T_v*dp/p
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pt = lane;
+  const size_t ie = (size_t)k.nets + blockIdx.x;
+  const size_t tl = (size_t)k.timelevels;
+  const int lev0 = w * TPW;
+  // Addressing as in caar_np4.hip: wave-uniform field pointers (element, time level and
+  // this wave's first level folded in) indexed by `r * PP + ulane`, r compile-time.
+  const unsigned ulane = lane;
+  const size_t wbase = (size_t)lev0 * PP;
+
+  const double* __restrict__ dp_n0 = k.dp3d + (ie * tl + k.n0) * BLK + wbase;
+  const double2* __restrict__ v_n0 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.n0) * BLK * 2) + wbase;
+  const double* __restrict__ T_n0 = k.T + (ie * tl + k.n0) * BLK + wbase;
+  const double* __restrict__ Qdp = k.Qdp + ((ie * k.qsize_d + 0) * 2 + (MOIST ? k.qn0 : 0)) * BLK + wbase;
+
+  // ---- phase 0: start the n0 loads; stage Dvv^T and the metric terms in LDS ----------
+  struct N0In {
+    double dp, T, q;
+    double2 uv;
+  };
+  auto load_n0 = [&](int r) {
+    const unsigned off = r * PP + ulane;
+    N0In x;
+    x.dp = dp_n0[off];
+    x.uv = v_n0[off];
+    x.T = T_n0[off];
+    x.q = MOIST ? Qdp[off] : 0.0;
+    return x;
+  };
+  constexpr int PD = TPW < 3 ? TPW : 3;  // levels in flight per wave
+  N0In ring[PD];
+#pragma unroll
+  for (int r = 0; r < PD; ++r) ring[r] = load_n0(r);
+  double T[TPW], Tv[TPW];
+  double* const park_dp = s_park + lev0 * PP + lane;  // + r*PP; u, v follow at BLK strides
+  // volatile reads: the compiler must not forward the parked values through registers
+  const volatile double* const park_rd = park_dp;
+  if (tid < 64) s_dvvT[(tid & 7) * NP + (tid >> 3)] = k.Dvv[tid];  // Dvv[k][j] -> dvvT[j][k]
+  for (int idx = tid; idx < G_SIZE; idx += THREADS) {
+    const double* src;
+    if (idx < G_SPHEREMP) src = k.fcor + ie * PP + idx;
+    else if (idx < G_METDET) src = k.spheremp + ie * PP + (idx - G_SPHEREMP);
+    else if (idx < G_RMETDET) src = k.metdet + ie * PP + (idx - G_METDET);
+    else if (idx < G_PHIS) src = k.rmetdet + ie * PP + (idx - G_RMETDET);
+    else if (idx < G_D) src = k.phis + ie * PP + (idx - G_PHIS);
+    else if (idx < G_DINV) src = k.D + ie * PP * 4 + (idx - G_D);
+    else src = k.Dinv + ie * PP * 4 + (idx - G_DINV);
+    s_geo[idx] = *src;
+  }
+  __syncthreads();
+
+  Ctx c;
+  c.tile = s_tile + w * 64;
+  c.a = lane >> 3;
+  c.b = lane & 7;
+#pragma unroll
+  for (int kk = 0; kk < NP; ++kk) {
+    c.ca[kk] = s_dvvT[c.a * NP + kk];
+    c.cb[kk] = s_dvvT[c.b * NP + kk];
+  }
+  const double rrearth = k.rrearth;
+  const double rmetdet = s_geo[G_RMETDET + pt];
+
+  // ---- phase 1: divdp, T_v; wave totals of dp and divdp -------------------------------
+  double divdp[TPW];
+  {
+    const M22 Dinv = load_m22(s_geo + G_DINV, pt);
+    const double metdet = s_geo[G_METDET + pt];
+    double run_dp = 0.0, run_div = 0.0;
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) {
+      const N0In x = ring[r % PD];
+      if (r + PD < TPW) ring[r % PD] = load_n0(r + PD);
+      divdp[r] = divergence_sphere(c, lane, Dinv, metdet, rmetdet, rrearth, x.uv.x * x.dp, x.uv.y * x.dp);  // P:114-121
+      T[r] = x.T;
+      Tv[r] = MOIST ? x.T * (1.0 + k.rv_over_rd_m1 * (x.q * recip(x.dp))) : x.T;  // P:135,150-151
+      run_dp += x.dp;
+      run_div += divdp[r];
+      park_dp[r * PP] = x.dp;
+      park_dp[BLK + r * PP] = x.uv.x;
+      park_dp[2 * BLK + r * PP] = x.uv.y;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    s_tot_dp[w * PP + pt] = run_dp;
+    s_tot_div[w * PP + pt] = run_div;
+  }
+  __syncthreads();
+
+  // ---- phase 2: hydrostatic increments, their suffix sums inside the wave ---------------
+  double base_dp = 0.0, base_div = 0.0;  // sums over the levels above this wave's first level
+  for (int w2 = 0; w2 < w; ++w2) {
+    base_dp += s_tot_dp[w2 * PP + pt];
+    base_div += s_tot_div[w2 * PP + pt];
+  }
+  double wave_ht;  // sum of the hydrostatic increments over this wave's levels
+  {
+    double run = base_dp, acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) {
+      const double dpr = park_rd[r * PP];
+      const double p = (k.p_top + run) + 0.5 * dpr;         // P:84,94-96 in closed form
+      run += dpr;
+      acc += (k.Rgas * Tv[r]) * (dpr * recip(p));           // Rgas*T_v*hkl, hkl = dp/p (P:300-302)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_ht = acc;
+    s_tot_ht[w * PP + pt] = acc;
+  }
+
+  const double2* __restrict__ v_nm1 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.nm1) * BLK * 2) + wbase;
+  const double* __restrict__ T_nm1 = k.T + (ie * tl + k.nm1) * BLK + wbase;
+  const double* __restrict__ dp_nm1 = k.dp3d + (ie * tl + k.nm1) * BLK + wbase;
+  double2* __restrict__ v_np1 = reinterpret_cast<double2*>(k.v + (ie * tl + k.np1) * BLK * 2) + wbase;
+  double* __restrict__ T_np1 = k.T + (ie * tl + k.np1) * BLK + wbase;
+  double* __restrict__ dp_np1 = k.dp3d + (ie * tl + k.np1) * BLK + wbase;
+  double2* __restrict__ vn0 = reinterpret_cast<double2*>(k.vn0 + ie * BLK * 2) + wbase;
+  double* __restrict__ omega_p = k.omega_p + ie * BLK + wbase;
+  double* __restrict__ phi_out = k.phi + ie * BLK + wbase;
+  const double* __restrict__ pecnd = k.pecnd + ie * BLK + wbase;
+  double* __restrict__ eta = k.eta_dot_dpdn + ie * (BLK + PP) + wbase;
+  double* __restrict__ eta_last = k.eta_dot_dpdn + ie * (BLK + PP) + BLK;
+
+  struct LevelIn {
+    double2 vnm1, vn0;
+    double Tnm1, dpnm1, om, pec, eta;
+  };
+  auto load_level = [&](int r) {
+    const unsigned off = r * PP + ulane;
+    LevelIn x;
+    x.vnm1 = v_nm1[off];
+    x.Tnm1 = T_nm1[off];
+    x.dpnm1 = dp_nm1[off];
+    x.vn0 = vn0[off];
+    x.om = omega_p[off];
+    x.pec = pecnd[off];
+    x.eta = eta[off];
+    return x;
+  };
+  LevelIn cur = load_level(0);  // in flight across the barrier
+  double l_eta_last = 0.0;
+  if (tid < PP) l_eta_last = eta_last[ulane];
+  __syncthreads();
+
+  // ---- phase 3: level-local tendencies and update, top level of the wave first ----------
+  double below = 0.0;  // hydrostatic sum over the waves below this one, bottom-up (P:293,302)
+  for (int w2 = WAVES - 1; w2 > w; --w2) below += s_tot_ht[w2 * PP + pt];
+  const M22 Dinv = load_m22(s_geo + G_DINV, pt);
+  const M22 Dm = load_m22(s_geo + G_D, pt);
+  const double fcor = s_geo[G_FCOR + pt];
+  const double spheremp = s_geo[G_SPHEREMP + pt];
+  const double phis = s_geo[G_PHIS + pt];
+  const double eta_zero = k.eta_ave_w * 0.0;  // eta_dot_dpdn_tmp == 0 (P:22,172)
+
+  double run_dp = base_dp, suml = base_div, run_ht = 0.0;
+#pragma unroll
+  for (int r = 0; r < TPW; ++r) {
+    const unsigned off = r * PP + ulane;
+    LevelIn nxt = cur;
+    if (r + 1 < TPW) nxt = load_level(r + 1);
+
+    const double dpr = park_rd[r * PP], ur = park_rd[BLK + r * PP], vr = park_rd[2 * BLK + r * PP];
+    const double Tr = T[r];
+
+    const double p = (k.p_top + run_dp) + 0.5 * dpr;
+    run_dp += dpr;
+    const double rp = recip(p);
+    const double ht = (k.Rgas * Tv[r]) * (dpr * rp);
+    run_ht += ht;  // same increments, same order as in phase 2
+    // levels below r inside this wave = wave total - inclusive prefix (P:302's phii)
+    const double phi = (phis + (below + (wave_ht - run_ht))) + 0.5 * ht;  // P:303,309
+
+    double gp0, gp1;
+    gradient_sphere(c, lane, Dinv, rrearth, p, gp0, gp1);              // P:103
+    const double vgrad_p = ur * gp0 + vr * gp1;                    // P:111
+    const double ckk = 0.5 * rp, ckl = rp;                             // P:333-334
+    const double om = vgrad_p * rp - ckl * suml - ckk * divdp[r];      // P:325,336,348
+    suml += divdp[r];                                                  // P:339
+    const double vort = vorticity_sphere(c, lane, Dm, rmetdet, rrearth, ur, vr);  // P:122
+
+    const double Ephi = 0.5 * (ur * ur + vr * vr) + phi + cur.pec;  // P:196
+    double gT0, gT1, gE0, gE1;
+    gradient_sphere(c, lane, Dinv, rrearth, Tr, gT0, gT1);           // P:200
+    const double vgrad_T = ur * gT0 + vr * gT1;                    // P:209
+    gradient_sphere(c, lane, Dinv, rrearth, Ephi, gE0, gE1);           // P:213
+    const double gpterm = Tv[r] * rp;                                  // P:219
+    const double glnps1 = k.Rgas * gpterm * gp0;                       // P:221
+    const double glnps2 = k.Rgas * gpterm * gp1;                       // P:222
+    const double vtens1 = vr * (fcor + vort) - gE0 - glnps1;         // P:227
+    const double vtens2 = -ur * (fcor + vort) - gE1 - glnps2;        // P:228
+    const double ttens = -vgrad_T + k.kappa * Tv[r] * om;              // P:230
+
+    double2 vo;
+    vo.x = spheremp * (cur.vnm1.x + k.dt2 * vtens1);                   // P:251
+    vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);                   // P:252
+    v_np1[off] = vo;
+    T_np1[off] = spheremp * (cur.Tnm1 + k.dt2 * ttens);                // P:253
+    dp_np1[off] = spheremp * (cur.dpnm1 - k.dt2 * divdp[r]);           // P:254
+    phi_out[off] = phi;
+    omega_p[off] = cur.om + k.eta_ave_w * om;                          // P:173
+    double2 vn;
+    vn.x = cur.vn0.x + k.eta_ave_w * (ur * dpr);                   // P:117
+    vn.y = cur.vn0.y + k.eta_ave_w * (vr * dpr);                   // P:118
+    vn0[off] = vn;
+    eta[off] = cur.eta + eta_zero;                                     // P:172
+    cur = nxt;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (tid < PP) eta_last[ulane] = l_eta_last + eta_zero;               // P:181
+}
+
+template <int NLEV, int TPW, int MINW>
+static hipError_t launch_np8(const KernelArgs& k, int num_elems, hipStream_t stream) {
+  constexpr int THREADS = NLEV / TPW * 64;
+  if (k.qn0 >= 0)
+    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+  else  // dry branch (P:128-139)
+    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+  return hipGetLastError();
+}
+
+// (non-const on purpose, see caar_np4.hip)
+KernelVariant kNp8Nlev72[] = {
+    {"caar_np8_kernel<72, 9, 1, true>", "8 waves x 9 levels", launch_np8<72, 9, 1>},
+    {"caar_np8_kernel<72, 18, 1, true>", "4 waves x 18 levels (one wave per SIMD, 512 registers)", launch_np8<72, 18, 1>},
+    {"caar_np8_kernel<72, 6, 1, true>", "12 waves x 6 levels", launch_np8<72, 6, 1>},
+    {"caar_np8_kernel<72, 12, 1, true>", "6 waves x 12 levels", launch_np8<72, 12, 1>},
+    {"caar_np8_kernel<72, 8, 1, true>", "9 waves x 8 levels", launch_np8<72, 8, 1>},
+};
+int kNp8Nlev72Count = sizeof(kNp8Nlev72) / sizeof(kNp8Nlev72[0]);
+
+}  // namespace caar
