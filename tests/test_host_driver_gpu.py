@@ -1,0 +1,68 @@
+"""The C++ host side on the GPU box: this repo's driver (reference CLI, device-resident
+loop) and — when it was built in the build container — the reference's OWN main.cpp linked
+against this repo's Homme::compute_and_apply_rhs (oracle/_ref/pointers_only_hip), i.e. the
+link-level drop-in of INTEGRATION.md.  Both must print the norms the CPU oracle computes."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def norms_in(text):
+    vals = [float(x) for x in re.findall(r"\|\|(?:v|T|dp)\|\|_2\s*=\s*([-+0-9.eE]+)", text)]
+    return [vals[i:i + 3] for i in range(0, len(vals), 3)]
+
+
+def oracle_norms(np_, nlev, ne, calls=1):
+    O = po.Oracle()
+    arrs = O.init_arrays(np_, nlev, 1, 3, ne)
+    sc = po.default_scalars(nlev)
+    Dvv = O.dvv_np4(False) if np_ == 4 else O.dvv_gll(np_)
+    before = O.state_norms(arrs, Dvv, sc)
+    for _ in range(calls):
+        O.compute_and_apply_rhs(arrs, Dvv, sc)
+    return before, O.state_norms(arrs, Dvv, sc)
+
+
+@pytest.mark.parametrize("np_,nlev,exe", [(4, 72, "caar_driver"), (4, 128, "caar_driver_np4_nlev128"),
+                                           (8, 72, "caar_driver_np8_nlev72")])
+def test_driver_prints_oracle_norms(np_, nlev, exe):
+    path = os.path.join(ROOT, "tinman_sandbox_amd", "host", exe)
+    if not os.path.exists(path):
+        from tinman_sandbox_amd import build
+        build.build_all()
+    out = subprocess.run([path, "--tinman-num-elems=5", "--tinman-num-exec=3"], check=True,
+                         capture_output=True, text=True, timeout=300).stdout
+    blocks = norms_in(out)
+    assert len(blocks) == 4, out  # host before, device before, device after, host after
+    before, after = oracle_norms(np_, nlev, 5)
+    assert np.allclose(blocks[0], before, rtol=1e-15, atol=0)
+    assert np.allclose(blocks[1], before, rtol=1e-15, atol=0)
+    assert np.allclose(blocks[2], after, rtol=1e-13, atol=0)
+    assert np.allclose(blocks[3], after, rtol=1e-13, atol=0)
+
+
+def test_reference_main_links_against_the_hip_path():
+    exe = os.path.join(ROOT, "oracle", "_ref", "pointers_only_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/pointers_only_hip is only built where /root/reference exists")
+    out = subprocess.run([exe, "--tinman-num-elems=7", "--tinman-num-exec=2"], check=True,
+                         capture_output=True, text=True, timeout=300).stdout
+    blocks = norms_in(out)
+    assert len(blocks) == 2, out
+    before, after = oracle_norms(4, 72, 7)
+    assert np.allclose(blocks[0], before, rtol=1e-15, atol=0)
+    assert np.allclose(blocks[1], after, rtol=1e-13, atol=0)
+    # and the norms the reference documents for 3 elements (SURVEY.md 8c, C++ double Dvv)
+    out3 = subprocess.run([exe, "--tinman-num-elems=3"], check=True, capture_output=True, text=True,
+                          timeout=300).stdout
+    b3 = norms_in(out3)
+    assert np.allclose(b3[1], [18713.369259834482, 309464.50301779778, 138286.74685809007], rtol=1e-13, atol=0)

@@ -45,16 +45,25 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
-def build_host_driver(force=False, verbose=False):
-    """C++ host mirror of the reference driver (host/): links libcaar_hip.so."""
-    srcs = [os.path.join(HOST, f) for f in sorted(os.listdir(HOST)) if f.endswith(".cpp")]
-    if not srcs:
-        return None
-    exe = os.path.join(HOST, "caar_driver")
-    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [LIB]
-    if force or _stale(exe, deps):
-        cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(HERE, "..", "include"), "-I" + HOST] + srcs + \
-              ["-L" + CSRC, "-lcaar_hip", "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+def build_host_driver(force=False, verbose=False, np_=4, nlev=72):
+    """C++ host side (host/): libhomme_caar.so = Homme::compute_and_apply_rhs(TestData&) and
+    the data model on top of libcaar_hip.so, and caar_driver, the reference driver's CLI."""
+    inc = ["-I" + os.path.join(HERE, "..", "include"), "-I" + HOST]
+    defs = ["-DCAAR_NP=%d" % np_, "-DCAAR_PLEV=%d" % nlev]
+    suffix = "" if (np_, nlev) == (4, 72) else "_np%d_nlev%d" % (np_, nlev)
+    shim = os.path.join(HOST, "libhomme_caar%s.so" % suffix)
+    exe = os.path.join(HOST, "caar_driver%s" % suffix)
+    hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")]
+    link = ["-L" + CSRC, "-lcaar_hip", "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"]
+    shim_srcs = [os.path.join(HOST, "homme_caar.cpp"), os.path.join(HOST, "homme_data.cpp")]
+    if force or _stale(shim, shim_srcs + hdrs + [LIB]):
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared"] + defs + inc + shim_srcs + link + ["-o", shim]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    if force or _stale(exe, [os.path.join(HOST, "caar_driver.cpp"), shim] + hdrs):
+        cmd = ["g++", "-std=c++17", "-O2"] + defs + inc + [os.path.join(HOST, "caar_driver.cpp")] + \
+              ["-L" + HOST, "-lhomme_caar%s" % suffix, "-Wl,-rpath," + HOST] + link + ["-o", exe]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
@@ -63,7 +72,8 @@ def build_host_driver(force=False, verbose=False):
 
 def build_all(force=False, verbose=False):
     lib = build_library(force, verbose)
-    build_host_driver(force, verbose)
+    for np_, nlev in ((4, 72), (4, 128), (8, 72)):
+        build_host_driver(force, verbose, np_, nlev)
     return lib
 
 

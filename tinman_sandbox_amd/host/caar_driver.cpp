@@ -1,0 +1,142 @@
+// caar_driver.cpp — standalone driver of the MI355X compute_and_apply_rhs, with the
+// reference driver's command line (compute_and_apply_rhs_test/cxx/pointers_only/
+// main.cpp:36-88: --tinman-num-elems= --tinman-num-exec= --tinman-dump-res= --tinman-help)
+// and its output (initial norms, timed loop, final norms).
+//
+// Differences from the reference's loop (main.cpp:113-121): the element arrays are
+// uploaded once and stay on the GPU for all executions (DeviceSession), the loop is
+// timed with HIP events, and --tinman-update-levels=yes rotates the time levels between
+// executions (the reference has the call commented out, main.cpp:118).
+#include <cctype>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <string>
+
+#include "caar.h"
+#include "homme_caar.hpp"
+
+namespace {
+
+bool starts_with(const char* s, const char* prefix) { return std::strncmp(s, prefix, std::strlen(prefix)) == 0; }
+
+bool all_digits(const char* s) {
+  if (!*s) return false;
+  for (; *s; ++s)
+    if (!std::isdigit(static_cast<unsigned char>(*s))) return false;
+  return true;
+}
+
+bool parse_yes_no(const char* arg, const char* val, bool* out) {
+  const std::string v(val);
+  if (v == "yes" || v == "YES") *out = true;
+  else if (v == "no" || v == "NO") *out = false;
+  else {
+    std::cout << " ERROR! Unrecognized command line option '" << arg << "'.\n"
+              << "        Run with '--tinman-help' to see the available options.\n";
+    return false;
+  }
+  return true;
+}
+
+void usage() {
+  std::cout << "+--------------------------------------------------------------------------+\n"
+            << "|                      TinMan command line arguments                       |\n"
+            << "+--------------------------------------------------------------------------+\n"
+            << "|  --tinman-num-elems=N      : the number of elements (default=10)         |\n"
+            << "|  --tinman-dump-res=val     : whether to dump results to file (default=no)|\n"
+            << "|  --tinman-num-exec=N       : number of times to execute (default=1)      |\n"
+            << "|  --tinman-update-levels=val: rotate time levels between runs (default=no)|\n"
+            << "|  --tinman-device=N         : HIP device to run on (default=0)            |\n"
+            << "|  --tinman-help             : prints this message                         |\n"
+            << "+--------------------------------------------------------------------------+\n";
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  using namespace Homme;
+  bool dump_res = false, update_levels = false;
+  int num_exec = 1, device = 0;
+
+  for (int i = 1; i < argc; ++i) {
+    const char* a = argv[i];
+    const char* eq = std::strchr(a, '=');
+    const char* val = eq ? eq + 1 : "";
+    if (starts_with(a, "--tinman-num-elems=")) {
+      if (!all_digits(val)) {
+        std::cerr << "Expecting an unsigned integer after '--tinman-num-elems='.\n";
+        return 1;
+      }
+      num_elems = std::atoi(val);
+    } else if (starts_with(a, "--tinman-num-exec=")) {
+      if (!all_digits(val)) {
+        std::cerr << "Expecting an unsigned integer after '--tinman-num-exec='.\n";
+        return 1;
+      }
+      num_exec = std::atoi(val);
+    } else if (starts_with(a, "--tinman-device=")) {
+      device = std::atoi(val);
+    } else if (starts_with(a, "--tinman-dump-res=")) {
+      if (!parse_yes_no(a, val, &dump_res)) return 1;
+    } else if (starts_with(a, "--tinman-update-levels=")) {
+      if (!parse_yes_no(a, val, &update_levels)) return 1;
+    } else if (starts_with(a, "--tinman-help")) {
+      usage();
+      return 0;
+    }
+  }
+  if (num_elems < 1) {
+    std::cerr << "Invalid number of elements: " << num_elems << std::endl;
+    return 1;
+  }
+  if (!caar_supported(np, nlev)) {
+    std::cerr << "No MI355X kernel is compiled for NP=" << np << " NLEV=" << nlev << ".\n";
+    return 1;
+  }
+
+  TestData data;
+  std::cout << " --- Initializing data...\n";
+  data.init_data();
+  print_results_2norm(data);
+
+  std::cout << " --- Uploading " << num_elems << " elements to HIP device " << device << "...\n";
+  DeviceSession gpu(data, num_elems, device);
+  real n[3];
+  gpu.state_norms(data, n);
+  std::cout << "   ---> Norms (device):\n"
+            << "          ||v||_2  = " << std::setprecision(17) << n[0] << "\n"
+            << "          ||T||_2  = " << std::setprecision(17) << n[1] << "\n"
+            << "          ||dp||_2 = " << std::setprecision(17) << n[2] << "\n";
+
+  std::cout << " --- Performing computations... (" << num_exec << " executions of the main loop on "
+            << num_elems << " elements)\n";
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < num_exec; ++i) {
+    gpu.run(data);
+    if (update_levels && i + 1 < num_exec) data.update_time_levels();
+  }
+  gpu.sync();
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::cout << "   ---> compute_and_apply_rhs execution total time: " << secs << " s  ("
+            << double(num_elems) * num_exec / secs << " element-updates/s, kernel "
+            << caar_kernel_name(np, nlev) << ")\n";
+
+  gpu.state_norms(data, n);
+  std::cout << "   ---> Norms (device):\n"
+            << "          ||v||_2  = " << std::setprecision(17) << n[0] << "\n"
+            << "          ||T||_2  = " << std::setprecision(17) << n[1] << "\n"
+            << "          ||dp||_2 = " << std::setprecision(17) << n[2] << "\n";
+  gpu.download(data);
+  print_results_2norm(data);
+
+  if (dump_res) {
+    std::cout << " --- Dumping results to file...\n";
+    dump_results_to_file(data);
+  }
+  std::cout << " --- Cleaning up data...\n";
+  data.cleanup_data();
+  return 0;
+}

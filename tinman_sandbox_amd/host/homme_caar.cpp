@@ -1,0 +1,202 @@
+// homme_caar.cpp — Homme::compute_and_apply_rhs and friends on top of include/caar.h.
+#include "homme_caar.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+
+#include "caar.h"
+
+namespace Homme {
+
+extern int num_elems;
+
+namespace {
+
+void check(int rc, const char* what) {
+  if (rc != CAAR_OK) {
+    // the reference's interface has no error channel (void return, P:15): fail loudly
+    std::fprintf(stderr, "caar: %s failed: %d (%s)\n", what, rc, caar_strerror(rc));
+    std::abort();
+  }
+}
+
+CaarDims dims_for(int ne) {
+  CaarDims d;
+  d.np = np;
+  d.nlev = nlev;
+  d.qsize_d = qsize_d;
+  d.timelevels = timelevels;
+  d.num_elems = ne;
+  return d;
+}
+
+CaarArrays host_arrays(const Arrays& a) {
+  CaarArrays h;
+  h.elem_D = a.elem_D;
+  h.elem_Dinv = a.elem_Dinv;
+  h.elem_fcor = a.elem_fcor;
+  h.elem_spheremp = a.elem_spheremp;
+  h.elem_metdet = a.elem_metdet;
+  h.elem_rmetdet = a.elem_rmetdet;
+  h.elem_state_dp3d = a.elem_state_dp3d;
+  h.elem_state_v = a.elem_state_v;
+  h.elem_state_T = a.elem_state_T;
+  h.elem_state_phis = a.elem_state_phis;
+  h.elem_state_Qdp = a.elem_state_Qdp;
+  h.elem_derived_eta_dot_dpdn = a.elem_derived_eta_dot_dpdn;
+  h.elem_derived_omega_p = a.elem_derived_omega_p;
+  h.elem_derived_phi = a.elem_derived_phi;
+  h.elem_derived_pecnd = a.elem_derived_pecnd;
+  h.elem_derived_vn0 = a.elem_derived_vn0;
+  return h;
+}
+
+CaarParams params_for(const TestData& d) {
+  CaarParams p;
+  p.nets = d.control.nets;
+  p.nete = d.control.nete;
+  p.n0 = d.control.n0;
+  p.np1 = d.control.np1;
+  p.nm1 = d.control.nm1;
+  p.qn0 = d.control.qn0;
+  p.dt2 = d.control.dt2;
+  p.rrearth = d.constants.rrearth;
+  p.eta_ave_w = d.constants.eta_ave_w;
+  p.Rwater_vapor = d.constants.Rwater_vapor;
+  p.Rgas = d.constants.Rgas;
+  p.kappa = d.constants.kappa;
+  p.ps0 = d.hvcoord.ps0;
+  p.hyai0 = d.hvcoord.hyai[0];
+  p.Dvv = &d.deriv.Dvv[0][0];
+  return p;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------- DeviceSession
+DeviceSession::DeviceSession(const TestData& data, int ne, int device) : ctx_(nullptr), num_elems_(ne) {
+  const CaarDims d = dims_for(ne);
+  if (!caar_supported(d.np, d.nlev)) check(CAAR_EUNSUPPORTED, "caar_supported(np, nlev)");
+  check(caar_create(&ctx_, &d, device), "caar_create");
+  upload(data);
+}
+
+DeviceSession::~DeviceSession() { caar_destroy(ctx_); }
+
+void DeviceSession::upload(const TestData& data) {
+  const CaarArrays h = host_arrays(data.arrays);
+  check(caar_upload(ctx_, &h, 0, num_elems_), "caar_upload");
+}
+
+void DeviceSession::run(const TestData& data) {
+  const CaarParams p = params_for(data);
+  check(caar_run(ctx_, &p), "caar_run");
+}
+
+void DeviceSession::sync() { check(caar_sync(ctx_), "caar_sync"); }
+
+void DeviceSession::download(TestData& data, bool all_arrays) {
+  const CaarArrays h = host_arrays(data.arrays);
+  check(caar_download(ctx_, &h, 0, num_elems_, all_arrays ? 1 : 0), "caar_download");
+  sync();
+}
+
+void DeviceSession::state_norms(const TestData& data, real out[3]) {
+  check(caar_state_norms(ctx_, data.control.np1, data.control.nets, data.control.nete, out), "caar_state_norms");
+}
+
+float DeviceSession::time_runs(const TestData& data, int reps) {
+  const CaarParams p = params_for(data);
+  float ms = 0.f;
+  check(caar_time_runs(ctx_, &p, reps, &ms), "caar_time_runs");
+  return ms;
+}
+
+// -------------------------------------------------- the reference's free functions
+// P:15.  Host arrays in, host arrays out.  The session is rebuilt when the element count
+// changes; every call uploads all arrays (the host may have changed any of them) and
+// downloads the seven the path mutates.  PCIe-bound by construction: hosts that step in
+// a loop should hold a DeviceSession instead.
+void compute_and_apply_rhs(TestData& data) {
+  static DeviceSession* session = nullptr;  // device buffers are kept between calls
+  static int session_elems = -1;
+  const int ne = data.control.nete > num_elems ? data.control.nete : num_elems;
+  if (!session || session_elems != ne) {
+    delete session;
+    session = new DeviceSession(data, ne);  // allocates and uploads
+    session_elems = ne;
+  } else {
+    session->upload(data);
+  }
+  session->run(data);
+  session->download(data);
+}
+
+// P:353-370
+real compute_norm(const real* const field, int length) {
+  real norm = 0, c = 0;
+  for (int i = 0; i < length; ++i) {
+    const real y = field[i] * field[i] - c;
+    const real t = norm + y;
+    c = (t - norm) - y;
+    norm = t;
+  }
+  return std::sqrt(norm);
+}
+
+// P:372-399 (host arrays; the device-resident equivalent is DeviceSession::state_norms)
+void print_results_2norm(const TestData& data) {
+  const std::size_t blk = std::size_t(nlev) * np * np;
+  real vn = 0, tn = 0, dn = 0;
+  for (int ie = data.control.nets; ie < data.control.nete; ++ie) {
+    const std::size_t slab = std::size_t(ie) * timelevels + data.control.np1;
+    vn += std::pow(compute_norm(data.arrays.elem_state_v + slab * blk * 2, int(blk * 2)), 2);
+    tn += std::pow(compute_norm(data.arrays.elem_state_T + slab * blk, int(blk)), 2);
+    dn += std::pow(compute_norm(data.arrays.elem_state_dp3d + slab * blk, int(blk)), 2);
+  }
+  std::cout << "   ---> Norms:\n"
+            << "          ||v||_2  = " << std::setprecision(17) << std::sqrt(vn) << "\n"
+            << "          ||T||_2  = " << std::setprecision(17) << std::sqrt(tn) << "\n"
+            << "          ||dp||_2 = " << std::setprecision(17) << std::sqrt(dn) << "\n";
+}
+
+// P:401-487: one text file per field, "[ie, ilev]" header then np rows of np values at
+// 6 significant digits.
+void dump_results_to_file(const TestData& data) {
+  struct Out {
+    const char* name;
+    const real* base;
+    int comps, comp;
+  };
+  const Out outs[] = {{"elem_state_vx.txt", data.arrays.elem_state_v, 2, 0},
+                      {"elem_state_vy.txt", data.arrays.elem_state_v, 2, 1},
+                      {"elem_state_t.txt", data.arrays.elem_state_T, 1, 0},
+                      {"elem_state_dp3d.txt", data.arrays.elem_state_dp3d, 1, 0}};
+  const std::size_t pp = std::size_t(np) * np, blk = pp * nlev;
+  for (const Out& o : outs) {
+    std::ofstream f(o.name);
+    if (!f.is_open()) {
+      std::cout << "Error! Cannot open '" << o.name << "'.\n";
+      std::abort();
+    }
+    f.precision(6);
+    for (int ie = data.control.nets; ie < data.control.nete; ++ie) {
+      const real* lev0 = o.base + (std::size_t(ie) * timelevels + data.control.np1) * blk * o.comps;
+      for (int k = 0; k < nlev; ++k) {
+        f << "[" << ie << ", " << k << "]\n";
+        for (int i = 0; i < np; ++i) {
+          for (int j = 0; j < np; ++j) f << " " << lev0[(k * pp + i * np + j) * o.comps + o.comp];
+          f << "\n";
+        }
+      }
+    }
+  }
+}
+
+}  // namespace Homme

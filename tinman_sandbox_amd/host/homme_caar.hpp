@@ -1,0 +1,61 @@
+// homme_caar.hpp — the reference's call surface for the hot path, on the MI355X.
+//
+//   Homme::compute_and_apply_rhs(TestData&)      drop-in for the reference's
+//       cxx/pointers_only/compute_and_apply_rhs.hpp:9 (host arrays in, host arrays out:
+//       upload -> HIP kernel -> download of the mutated arrays), and the three helpers
+//       its main.cpp also links (compute_norm :19, print_results_2norm :21,
+//       dump_results_to_file :23);
+//   Homme::DeviceSession                          the same call with the element arrays
+//       kept resident on the GPU between calls (what a time-stepping host wants, and
+//       what the driver's timed loop uses).
+//
+// Build with -DCAAR_USE_REFERENCE_HEADERS and the reference's include path to compile
+// this file against the reference's own data_structures.hpp (link-level drop-in for the
+// reference's main.cpp); otherwise homme_data.hpp is used.
+#ifndef HOMME_CAAR_HPP
+#define HOMME_CAAR_HPP
+
+#ifdef CAAR_USE_REFERENCE_HEADERS
+#include "data_structures.hpp"
+#else
+#include "homme_data.hpp"
+#endif
+
+struct CaarContext;
+
+namespace Homme {
+
+void compute_and_apply_rhs(TestData& data);
+real compute_norm(const real* const field, int length);
+void print_results_2norm(const TestData& data);
+void dump_results_to_file(const TestData& data);
+
+// Element arrays resident on one GPU.  Not copyable; all calls from one thread.
+class DeviceSession {
+ public:
+  // uploads all 16 arrays of `data` (num_elems elements) to HIP device `device`
+  explicit DeviceSession(const TestData& data, int num_elems, int device = 0);
+  ~DeviceSession();
+  DeviceSession(const DeviceSession&) = delete;
+  DeviceSession& operator=(const DeviceSession&) = delete;
+
+  // host -> device copy of all 16 arrays again (after the host changed them)
+  void upload(const TestData& data);
+  // one compute_and_apply_rhs with data's current Control/Constants/HVCoord/Derivative;
+  // asynchronous, ordered on the session's stream
+  void run(const TestData& data);
+  void sync();
+  // copy the arrays the kernel mutates (all_arrays: every array) back into data's host arrays
+  void download(TestData& data, bool all_arrays = false);
+  // print_results_2norm's numbers for time level control.np1, computed on the device
+  void state_norms(const TestData& data, real out[3]);
+  // milliseconds for `reps` back-to-back runs (HIP events on the session stream)
+  float time_runs(const TestData& data, int reps);
+
+ private:
+  CaarContext* ctx_;
+  int num_elems_;
+};
+
+}  // namespace Homme
+#endif
