@@ -171,10 +171,8 @@ def main():
     wall = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
 
-    tmax = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall_max, kernel_ms_max = tmax.tolist()
+    from tinman_sandbox_amd import sharding
+    wall_max, kernel_ms_max = sharding.max_over_ranks([wall, kernel_ms], dist, dev)
 
     if rank == 0:
         balg = tsa.algorithmic_bytes(args.np_, args.nlev)
