@@ -135,11 +135,12 @@ const char *caar_variant_info(int np, int nlev, int variant);
  * HBM ceiling next to the spec peak and the calibration run for the HBM PMC counters.
  * caar_traffic_skeleton: touches exactly the bytes caar_launch touches (NP=4), same
  * addressing and access widths, no arithmetic; it OVERWRITES the output arrays with
- * meaningless values. */
+ * meaningless values.  `variant` picks the launch shape / cache policy being probed
+ * (0 = the shape of the default kernel); unknown variants return hipErrorInvalidValue. */
 int caar_stream_copy(double *dst_dev, const double *src_dev, long long n_doubles, int lane_bytes,
                      void *stream);
 int caar_traffic_skeleton(const CaarDims *dims, const CaarArrays *dev, const CaarParams *params,
-                          void *stream);
+                          int variant, void *stream);
 
 /* ---- context API: the library owns the device copies ---------------------------
  * What Homme::compute_and_apply_rhs(TestData&) needs when TestData lives in host

@@ -92,7 +92,7 @@ class CaarLibrary:
         L.caar_variant_info.restype = C.c_char_p
         L.caar_stream_copy.argtypes = [vp, vp, C.c_longlong, C.c_int, vp]
         L.caar_traffic_skeleton.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays),
-                                            C.POINTER(_CaarParams), vp]
+                                            C.POINTER(_CaarParams), C.c_int, vp]
         L.caar_create.argtypes = [C.POINTER(vp), C.POINTER(_CaarDims), C.c_int]
         L.caar_destroy.argtypes = [vp]
         L.caar_destroy.restype = None

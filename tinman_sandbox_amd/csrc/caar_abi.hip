@@ -26,7 +26,7 @@ hipError_t launch_state_norms(const double* v, const double* T, const double* dp
 
 hipError_t launch_stream_copy(double* dst, const double* src, size_t n_doubles, int lane_bytes,
                               hipStream_t stream);
-hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int num_elems, hipStream_t stream);
+hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t stream);
 
 struct Config {
   int np, nlev;
@@ -216,7 +216,8 @@ int caar_stream_copy(double* dst_dev, const double* src_dev, long long n_doubles
   return (int)caar::launch_stream_copy(dst_dev, src_dev, (size_t)n_doubles, lane_bytes, (hipStream_t)stream);
 }
 
-int caar_traffic_skeleton(const CaarDims* dims, const CaarArrays* dev, const CaarParams* p, void* stream) {
+int caar_traffic_skeleton(const CaarDims* dims, const CaarArrays* dev, const CaarParams* p, int variant,
+                          void* stream) {
   int rc = check_common(dims, p);
   if (rc) return rc;
   if (!dev || dims->np != 4) return CAAR_EUNSUPPORTED;
@@ -225,7 +226,7 @@ int caar_traffic_skeleton(const CaarDims* dims, const CaarArrays* dev, const Caa
   if (p->nete == p->nets) return CAAR_OK;
   caar::KernelArgs k;
   fill_args_impl(k, dims, dev, nullptr, p);
-  return (int)caar::launch_traffic_skeleton(k, dims->nlev, p->nete - p->nets, (hipStream_t)stream);
+  return (int)caar::launch_traffic_skeleton(k, dims->nlev, variant, p->nete - p->nets, (hipStream_t)stream);
 }
 
 int caar_launch_state_norms(const CaarDims* d, const CaarArrays* dev, int tl, int e0, int e1,

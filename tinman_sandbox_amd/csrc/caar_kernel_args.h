@@ -53,6 +53,22 @@ __device__ __forceinline__ double recip(double x) {
   return r;
 }
 
+// Streaming accesses.  Every element array is read once and written once per launch
+// and never re-used by another workgroup, so the loads and stores carry the
+// non-temporal hint ("nt"): measured +5..8 % bandwidth on the traffic skeleton when
+// BOTH loads and stores are non-temporal (profiles/r01/kbench_skeleton_nt.log).
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+template <bool NT, typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void stream_store(T* p, T v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 // One compiled kernel configuration for a given (np, nlev).
 struct KernelVariant {
   const char* kernel;  // demangled kernel name as rocprofv3 prints it

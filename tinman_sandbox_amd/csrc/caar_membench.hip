@@ -33,61 +33,121 @@ hipError_t launch_stream_copy(double* dst, const double* src, size_t n_doubles, 
   return hipGetLastError();
 }
 
-template <int NLEV, int TPW>
+template <bool NT, typename T>
+__device__ __forceinline__ T ld(const T* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void st(T* p, T v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+__device__ __forceinline__ double2 ld2(const double2* p, bool) { return *p; }
+
+// NTL / NTS: non-temporal loads / stores; ALL_FIRST: issue every load of the element
+// before the first store (maximum bytes in flight) instead of tile by tile.
+template <int NLEV, int TPW, bool NTL, bool NTS, bool ALL_FIRST>
 __global__ __launch_bounds__(NLEV / 4 / TPW * 64) void traffic_skeleton_np4(const KernelArgs k) {
-  constexpr int PP = 16, NT = NLEV / 4, BLK = NLEV * PP;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pt = lane & 15;
+  constexpr int PP = 16, BLK = NLEV * PP;
+  const int tid = threadIdx.x, lane = tid & 63, pt = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned ulane = lane;
   const size_t ie = (size_t)k.nets + blockIdx.x, tl = (size_t)k.timelevels;
-  const double* dp_n0 = k.dp3d + (ie * tl + k.n0) * BLK;
-  const double2* v_n0 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.n0) * BLK * 2);
-  const double* T_n0 = k.T + (ie * tl + k.n0) * BLK;
-  const double* Qdp = k.Qdp + ((ie * k.qsize_d + 0) * 2 + (k.qn0 >= 0 ? k.qn0 : 0)) * BLK;
-  const double2* v_nm1 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.nm1) * BLK * 2);
-  const double* T_nm1 = k.T + (ie * tl + k.nm1) * BLK;
-  const double* dp_nm1 = k.dp3d + (ie * tl + k.nm1) * BLK;
-  double2* v_np1 = reinterpret_cast<double2*>(k.v + (ie * tl + k.np1) * BLK * 2);
-  double* T_np1 = k.T + (ie * tl + k.np1) * BLK;
-  double* dp_np1 = k.dp3d + (ie * tl + k.np1) * BLK;
-  double2* vn0 = reinterpret_cast<double2*>(k.vn0 + ie * BLK * 2);
-  double* omega_p = k.omega_p + ie * BLK;
-  double* phi = k.phi + ie * BLK;
-  const double* pecnd = k.pecnd + ie * BLK;
-  double* eta = k.eta_dot_dpdn + ie * (BLK + PP);
+  const size_t wb = (size_t)w * (TPW * 64);
+  const double* dp_n0 = k.dp3d + (ie * tl + k.n0) * BLK + wb;
+  const double* vv_n0 = k.v + ((ie * tl + k.n0) * BLK + wb) * 2;
+  const double* T_n0 = k.T + (ie * tl + k.n0) * BLK + wb;
+  const double* Qdp = k.Qdp + ((ie * k.qsize_d + 0) * 2 + (k.qn0 >= 0 ? k.qn0 : 0)) * BLK + wb;
+  const double* vv_nm1 = k.v + ((ie * tl + k.nm1) * BLK + wb) * 2;
+  const double* T_nm1 = k.T + (ie * tl + k.nm1) * BLK + wb;
+  const double* dp_nm1 = k.dp3d + (ie * tl + k.nm1) * BLK + wb;
+  double* vv_np1 = k.v + ((ie * tl + k.np1) * BLK + wb) * 2;
+  double* T_np1 = k.T + (ie * tl + k.np1) * BLK + wb;
+  double* dp_np1 = k.dp3d + (ie * tl + k.np1) * BLK + wb;
+  double* vvn0 = k.vn0 + (ie * BLK + wb) * 2;
+  double* omega_p = k.omega_p + ie * BLK + wb;
+  double* phi = k.phi + ie * BLK + wb;
+  const double* pecnd = k.pecnd + ie * BLK + wb;
+  double* eta = k.eta_dot_dpdn + ie * (BLK + PP) + wb;
+  double* eta_last = k.eta_dot_dpdn + ie * (BLK + PP) + BLK;
+  typedef double v2 __attribute__((ext_vector_type(2)));
   // 13 metric values per point, read by every lane like the real kernel's LDS staging source
   double g = k.fcor[ie * PP + pt] + k.spheremp[ie * PP + pt] + k.metdet[ie * PP + pt] +
              k.rmetdet[ie * PP + pt] + k.phis[ie * PP + pt];
 #pragma unroll
   for (int j = 0; j < 4; ++j) g += k.D[(ie * PP + pt) * 4 + j] + k.Dinv[(ie * PP + pt) * 4 + j];
   g *= 0.0;
+  double a[TPW], tn[TPW], dn[TPW], om[TPW], et[TPW];
+  v2 uv[TPW], um[TPW], un[TPW];
 #pragma unroll
   for (int r = 0; r < TPW; ++r) {
-    const int off = (w * TPW + r) * 64 + lane;
-    const double a = dp_n0[off] + T_n0[off] + Qdp[off] + pecnd[off] + g;
-    const double2 uv = v_n0[off], um = v_nm1[off], un = vn0[off];
-    double2 o;
-    o.x = uv.x + um.x;
-    o.y = uv.y + um.y;
-    v_np1[off] = o;
-    T_np1[off] = T_nm1[off] + a;
-    dp_np1[off] = dp_nm1[off] + a;
-    phi[off] = a;
-    omega_p[off] = omega_p[off] + a * 0.0;
-    o.x = un.x + a * 0.0;
-    o.y = un.y;
-    vn0[off] = o;
-    eta[off] = eta[off] + 0.0;
+    const unsigned off = r * 64 + ulane;
+    a[r] = ld<NTL>(dp_n0 + off) + ld<NTL>(T_n0 + off) + ld<NTL>(Qdp + off) + ld<NTL>(pecnd + off) + g;
+    uv[r] = ld<NTL>(reinterpret_cast<const v2*>(vv_n0) + off);
+    um[r] = ld<NTL>(reinterpret_cast<const v2*>(vv_nm1) + off);
+    un[r] = ld<NTL>(reinterpret_cast<const v2*>(vvn0) + off);
+    tn[r] = ld<NTL>(T_nm1 + off);
+    dn[r] = ld<NTL>(dp_nm1 + off);
+    om[r] = ld<NTL>(omega_p + off);
+    et[r] = ld<NTL>(eta + off);
+    if (!ALL_FIRST) {
+      st<NTS>(reinterpret_cast<v2*>(vv_np1) + off, uv[r] + um[r]);
+      st<NTS>(T_np1 + off, tn[r] + a[r]);
+      st<NTS>(dp_np1 + off, dn[r] + a[r]);
+      st<NTS>(phi + off, a[r]);
+      st<NTS>(omega_p + off, om[r] + a[r] * 0.0);
+      st<NTS>(reinterpret_cast<v2*>(vvn0) + off, un[r]);
+      st<NTS>(eta + off, et[r] + 0.0);
+    }
   }
-  if (tid < PP) eta[BLK + tid] = eta[BLK + tid] + 0.0;
-  (void)NT;
+  if (ALL_FIRST) {
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) {
+      const unsigned off = r * 64 + ulane;
+      st<NTS>(reinterpret_cast<v2*>(vv_np1) + off, uv[r] + um[r]);
+      st<NTS>(T_np1 + off, tn[r] + a[r]);
+      st<NTS>(dp_np1 + off, dn[r] + a[r]);
+      st<NTS>(phi + off, a[r]);
+      st<NTS>(omega_p + off, om[r] + a[r] * 0.0);
+      st<NTS>(reinterpret_cast<v2*>(vvn0) + off, un[r]);
+      st<NTS>(eta + off, et[r] + 0.0);
+    }
+  }
+  if (tid < PP) eta_last[ulane] = eta_last[ulane] + 0.0;
 }
 
-hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int num_elems, hipStream_t stream) {
-  if (nlev == 72)
-    hipLaunchKernelGGL((traffic_skeleton_np4<72, 3>), dim3(num_elems), dim3(384), 0, stream, k);
-  else if (nlev == 128)
-    hipLaunchKernelGGL((traffic_skeleton_np4<128, 4>), dim3(num_elems), dim3(512), 0, stream, k);
-  else
+template <int NLEV, int TPW, bool NTL, bool NTS, bool AF>
+static void skel(const KernelArgs& k, int n, hipStream_t s) {
+  hipLaunchKernelGGL((traffic_skeleton_np4<NLEV, TPW, NTL, NTS, AF>), dim3(n), dim3(NLEV / 4 / TPW * 64), 0, s, k);
+}
+
+hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t s) {
+  if (nlev == 72) {
+    switch (variant) {
+      case 0: skel<72, 3, false, false, false>(k, num_elems, s); break;
+      case 1: skel<72, 2, false, false, false>(k, num_elems, s); break;
+      case 2: skel<72, 6, false, false, false>(k, num_elems, s); break;
+      case 3: skel<72, 3, true, true, false>(k, num_elems, s); break;
+      case 4: skel<72, 3, false, true, false>(k, num_elems, s); break;
+      case 5: skel<72, 3, true, false, false>(k, num_elems, s); break;
+      case 6: skel<72, 3, false, false, true>(k, num_elems, s); break;
+      case 7: skel<72, 2, false, false, true>(k, num_elems, s); break;
+      case 8: skel<72, 2, true, true, true>(k, num_elems, s); break;
+      case 9: skel<72, 9, false, false, true>(k, num_elems, s); break;
+      default: return hipErrorInvalidValue;
+    }
+  } else if (nlev == 128) {
+    switch (variant) {
+      case 0: skel<128, 4, false, false, false>(k, num_elems, s); break;
+      case 1: skel<128, 2, false, false, false>(k, num_elems, s); break;
+      case 2: skel<128, 4, true, true, false>(k, num_elems, s); break;
+      case 3: skel<128, 4, false, false, true>(k, num_elems, s); break;
+      default: return hipErrorInvalidValue;
+    }
+  } else {
     return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

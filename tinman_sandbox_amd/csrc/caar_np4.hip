@@ -119,7 +119,7 @@ __device__ __forceinline__ void scan_up(double x, int lane, int sub, double& inc
 // LDS image of the element's metric terms: 13 values per GLL point
 enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, G_D = 80, G_DINV = 144, G_SIZE = 208 };
 
-template <int NLEV, int TPW, int MINW, bool MOIST>
+template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT>
 __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
   constexpr int PP = 16;               // GLL points per level
   constexpr int NT = NLEV / 4;         // tiles per element
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
   const size_t wbase = (size_t)w * (TPW * 64);  // first point of this wave's tiles inside a field block
 
   const double* __restrict__ dp_n0 = k.dp3d + (ie * tl + k.n0) * BLK + wbase;
-  const double2* __restrict__ v_n0 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.n0) * BLK * 2) + wbase;
+  const dbl2* __restrict__ v_n0 = reinterpret_cast<const dbl2*>(k.v + (ie * tl + k.n0) * BLK * 2) + wbase;
   const double* __restrict__ T_n0 = k.T + (ie * tl + k.n0) * BLK + wbase;
   const double* __restrict__ Qdp = k.Qdp + ((ie * k.qsize_d + 0) * 2 + (MOIST ? k.qn0 : 0)) * BLK + wbase;
 
@@ -157,12 +157,12 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
   double dp[TPW], u[TPW], v[TPW], T[TPW], q[TPW];
 #pragma unroll
   for (int r = 0; r < TPW; ++r) {
-    dp[r] = dp_n0[r * 64 + ulane];
-    const double2 uv = v_n0[r * 64 + ulane];
+    dp[r] = stream_load<SNT>(dp_n0 + r * 64 + ulane);
+    const dbl2 uv = stream_load<SNT>(v_n0 + r * 64 + ulane);
     u[r] = uv.x;
     v[r] = uv.y;
-    T[r] = T_n0[r * 64 + ulane];
-    q[r] = MOIST ? Qdp[r * 64 + ulane] : 0.0;
+    T[r] = stream_load<SNT>(T_n0 + r * 64 + ulane);
+    q[r] = MOIST ? stream_load<SNT>(Qdp + r * 64 + ulane) : 0.0;
   }
   if (tid < 16) s_dvv[tid] = k.Dvv[tid];
   for (int idx = tid; idx < G_SIZE; idx += THREADS) {
@@ -239,13 +239,13 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
   }
 
   // pointers of the update phase
-  const double2* __restrict__ v_nm1 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.nm1) * BLK * 2) + wbase;
+  const dbl2* __restrict__ v_nm1 = reinterpret_cast<const dbl2*>(k.v + (ie * tl + k.nm1) * BLK * 2) + wbase;
   const double* __restrict__ T_nm1 = k.T + (ie * tl + k.nm1) * BLK + wbase;
   const double* __restrict__ dp_nm1 = k.dp3d + (ie * tl + k.nm1) * BLK + wbase;
-  double2* __restrict__ v_np1 = reinterpret_cast<double2*>(k.v + (ie * tl + k.np1) * BLK * 2) + wbase;
+  dbl2* __restrict__ v_np1 = reinterpret_cast<dbl2*>(k.v + (ie * tl + k.np1) * BLK * 2) + wbase;
   double* __restrict__ T_np1 = k.T + (ie * tl + k.np1) * BLK + wbase;
   double* __restrict__ dp_np1 = k.dp3d + (ie * tl + k.np1) * BLK + wbase;
-  double2* __restrict__ vn0 = reinterpret_cast<double2*>(k.vn0 + ie * BLK * 2) + wbase;
+  dbl2* __restrict__ vn0 = reinterpret_cast<dbl2*>(k.vn0 + ie * BLK * 2) + wbase;
   double* __restrict__ omega_p = k.omega_p + ie * BLK + wbase;
   double* __restrict__ phi_out = k.phi + ie * BLK + wbase;
   const double* __restrict__ pecnd = k.pecnd + ie * BLK + wbase;
@@ -255,19 +255,19 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
   // Update-phase inputs of one tile; loaded one tile ahead of their use so that only
   // two tiles' worth of them are ever live (register budget: 2 workgroups per CU).
   struct TileIn {
-    double2 vnm1, vn0;
+    dbl2 vnm1, vn0;
     double Tnm1, dpnm1, om, pec, eta;
   };
   auto load_tile = [&](int r) {
     const unsigned off = r * 64 + ulane;
     TileIn x;
-    x.vnm1 = v_nm1[off];
-    x.Tnm1 = T_nm1[off];
-    x.dpnm1 = dp_nm1[off];
-    x.vn0 = vn0[off];
-    x.om = omega_p[off];
-    x.pec = pecnd[off];
-    x.eta = eta[off];
+    x.vnm1 = stream_load<SNT>(v_nm1 + off);
+    x.Tnm1 = stream_load<SNT>(T_nm1 + off);
+    x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
+    x.vn0 = stream_load<SNT>(vn0 + off);
+    x.om = stream_load<SNT>(omega_p + off);
+    x.pec = stream_load<SNT>(pecnd + off);
+    x.eta = stream_load<SNT>(eta + off);
     return x;
   };
   TileIn cur = load_tile(TPW - 1);  // in flight across the barrier
@@ -320,53 +320,54 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
     const double vtens2 = -u[r] * (fcor + vort) - gE1 - glnps2;   // P:228
     const double ttens = -vgrad_T + k.kappa * Tv[r] * om;         // P:230 (T_vadv == 0)
 
-    double2 vo;
+    dbl2 vo;
     vo.x = spheremp * (cur.vnm1.x + k.dt2 * vtens1);              // P:251
     vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);              // P:252
-    v_np1[off] = vo;
-    T_np1[off] = spheremp * (cur.Tnm1 + k.dt2 * ttens);           // P:253
-    dp_np1[off] = spheremp * (cur.dpnm1 - k.dt2 * divdp[r]);      // P:254
-    phi_out[off] = phi;                                           // P:294,303,309
-    omega_p[off] = cur.om + k.eta_ave_w * om;                     // P:173
-    double2 vn;
+    stream_store<SNT>(v_np1 + off, vo);
+    stream_store<SNT>(T_np1 + off, spheremp * (cur.Tnm1 + k.dt2 * ttens));        // P:253
+    stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * divdp[r]));   // P:254
+    stream_store<SNT>(phi_out + off, phi);                                        // P:294,303,309
+    stream_store<SNT>(omega_p + off, cur.om + k.eta_ave_w * om);                  // P:173
+    dbl2 vn;
     vn.x = cur.vn0.x + k.eta_ave_w * (u[r] * dp[r]);              // P:117
     vn.y = cur.vn0.y + k.eta_ave_w * (v[r] * dp[r]);              // P:118
-    vn0[off] = vn;
-    eta[off] = cur.eta + eta_zero;                                // P:172
+    stream_store<SNT>(vn0 + off, vn);
+    stream_store<SNT>(eta + off, cur.eta + eta_zero);              // P:172
     cur = nxt;
   }
   if (tid < PP) eta_last[ulane] = l_eta_last + eta_zero;          // P:181
 }
 
 // explicit instantiations + launchers --------------------------------------------------
-template <int NLEV, int TPW, int MINW>
+template <int NLEV, int TPW, int MINW, bool NT>
 static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = NLEV / 4 / TPW * 64;
   if (k.qn0 >= 0)
-    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true, NT>), dim3(num_elems), dim3(THREADS), 0, stream, k);
   else  // dry branch (P:128-139): the Qdp block is never touched
-    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false, NT>), dim3(num_elems), dim3(THREADS), 0, stream, k);
   return hipGetLastError();
 }
 
 // Tuning variants (caar_select_variant): TPW = tiles per wave, MINW = waves per SIMD the
-// register allocator must leave room for (=> workgroups per CU).  Index 0 is the default.
+// register allocator must leave room for (=> workgroups per CU), NT = non-temporal
+// streaming accesses.  Index 0 is the default.
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
-    {"caar_np4_kernel<72, 2, 1, true>", "9 waves x 2 tiles", launch_np4<72, 2, 1>},
-    {"caar_np4_kernel<72, 2, 4, true>", "9 waves x 2 tiles, <=128 VGPR", launch_np4<72, 2, 4>},
-    {"caar_np4_kernel<72, 3, 3, true>", "6 waves x 3 tiles, <=168 VGPR: 2 workgroups/CU", launch_np4<72, 3, 3>},
-    {"caar_np4_kernel<72, 3, 1, true>", "6 waves x 3 tiles", launch_np4<72, 3, 1>},
-    {"caar_np4_kernel<72, 6, 1, true>", "3 waves x 6 tiles", launch_np4<72, 6, 1>},
+    {"caar_np4_kernel<72, 2, 1, true, true>", "9 waves x 2 tiles, nt", launch_np4<72, 2, 1, true>},
+    {"caar_np4_kernel<72, 2, 1, true, false>", "9 waves x 2 tiles", launch_np4<72, 2, 1, false>},
+    {"caar_np4_kernel<72, 3, 3, true, true>", "6 waves x 3 tiles, <=168 VGPR: 2 workgroups/CU, nt", launch_np4<72, 3, 3, true>},
+    {"caar_np4_kernel<72, 3, 1, true, true>", "6 waves x 3 tiles, nt", launch_np4<72, 3, 1, true>},
+    {"caar_np4_kernel<72, 6, 1, true, true>", "3 waves x 6 tiles, nt", launch_np4<72, 6, 1, true>},
 };
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
-    {"caar_np4_kernel<128, 4, 2, true>", "8 waves x 4 tiles", launch_np4<128, 4, 2>},
-    {"caar_np4_kernel<128, 2, 1, true>", "16 waves x 2 tiles", launch_np4<128, 2, 1>},
-    {"caar_np4_kernel<128, 8, 1, true>", "4 waves x 8 tiles", launch_np4<128, 8, 1>},
-    {"caar_np4_kernel<128, 4, 3, true>", "8 waves x 4 tiles, <=168 VGPR", launch_np4<128, 4, 3>},
+    {"caar_np4_kernel<128, 4, 2, true, true>", "8 waves x 4 tiles, nt", launch_np4<128, 4, 2, true>},
+    {"caar_np4_kernel<128, 4, 2, true, false>", "8 waves x 4 tiles", launch_np4<128, 4, 2, false>},
+    {"caar_np4_kernel<128, 2, 1, true, true>", "16 waves x 2 tiles, nt", launch_np4<128, 2, 1, true>},
+    {"caar_np4_kernel<128, 8, 1, true, true>", "4 waves x 8 tiles, nt", launch_np4<128, 8, 1, true>},
 };
 int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 

@@ -110,7 +110,7 @@ __device__ __forceinline__ double vorticity_sphere(const Ctx& c, int lane, const
 
 }  // namespace np8
 
-template <int NLEV, int TPW, int MINW, bool MOIST>
+template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT>
 __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const KernelArgs k) {
   using namespace np8;
   constexpr int WAVES = NLEV / TPW;
@@ -139,22 +139,22 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   const size_t wbase = (size_t)lev0 * PP;
 
   const double* __restrict__ dp_n0 = k.dp3d + (ie * tl + k.n0) * BLK + wbase;
-  const double2* __restrict__ v_n0 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.n0) * BLK * 2) + wbase;
+  const dbl2* __restrict__ v_n0 = reinterpret_cast<const dbl2*>(k.v + (ie * tl + k.n0) * BLK * 2) + wbase;
   const double* __restrict__ T_n0 = k.T + (ie * tl + k.n0) * BLK + wbase;
   const double* __restrict__ Qdp = k.Qdp + ((ie * k.qsize_d + 0) * 2 + (MOIST ? k.qn0 : 0)) * BLK + wbase;
 
   // ---- phase 0: start the n0 loads; stage Dvv^T and the metric terms in LDS ----------
   struct N0In {
     double dp, T, q;
-    double2 uv;
+    dbl2 uv;
   };
   auto load_n0 = [&](int r) {
     const unsigned off = r * PP + ulane;
     N0In x;
-    x.dp = dp_n0[off];
-    x.uv = v_n0[off];
-    x.T = T_n0[off];
-    x.q = MOIST ? Qdp[off] : 0.0;
+    x.dp = stream_load<SNT>(dp_n0 + off);
+    x.uv = stream_load<SNT>(v_n0 + off);
+    x.T = stream_load<SNT>(T_n0 + off);
+    x.q = MOIST ? stream_load<SNT>(Qdp + off) : 0.0;
     return x;
   };
   constexpr int PD = TPW < 3 ? TPW : 3;  // levels in flight per wave
@@ -237,13 +237,13 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     s_tot_ht[w * PP + pt] = acc;
   }
 
-  const double2* __restrict__ v_nm1 = reinterpret_cast<const double2*>(k.v + (ie * tl + k.nm1) * BLK * 2) + wbase;
+  const dbl2* __restrict__ v_nm1 = reinterpret_cast<const dbl2*>(k.v + (ie * tl + k.nm1) * BLK * 2) + wbase;
   const double* __restrict__ T_nm1 = k.T + (ie * tl + k.nm1) * BLK + wbase;
   const double* __restrict__ dp_nm1 = k.dp3d + (ie * tl + k.nm1) * BLK + wbase;
-  double2* __restrict__ v_np1 = reinterpret_cast<double2*>(k.v + (ie * tl + k.np1) * BLK * 2) + wbase;
+  dbl2* __restrict__ v_np1 = reinterpret_cast<dbl2*>(k.v + (ie * tl + k.np1) * BLK * 2) + wbase;
   double* __restrict__ T_np1 = k.T + (ie * tl + k.np1) * BLK + wbase;
   double* __restrict__ dp_np1 = k.dp3d + (ie * tl + k.np1) * BLK + wbase;
-  double2* __restrict__ vn0 = reinterpret_cast<double2*>(k.vn0 + ie * BLK * 2) + wbase;
+  dbl2* __restrict__ vn0 = reinterpret_cast<dbl2*>(k.vn0 + ie * BLK * 2) + wbase;
   double* __restrict__ omega_p = k.omega_p + ie * BLK + wbase;
   double* __restrict__ phi_out = k.phi + ie * BLK + wbase;
   const double* __restrict__ pecnd = k.pecnd + ie * BLK + wbase;
@@ -251,19 +251,19 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   double* __restrict__ eta_last = k.eta_dot_dpdn + ie * (BLK + PP) + BLK;
 
   struct LevelIn {
-    double2 vnm1, vn0;
+    dbl2 vnm1, vn0;
     double Tnm1, dpnm1, om, pec, eta;
   };
   auto load_level = [&](int r) {
     const unsigned off = r * PP + ulane;
     LevelIn x;
-    x.vnm1 = v_nm1[off];
-    x.Tnm1 = T_nm1[off];
-    x.dpnm1 = dp_nm1[off];
-    x.vn0 = vn0[off];
-    x.om = omega_p[off];
-    x.pec = pecnd[off];
-    x.eta = eta[off];
+    x.vnm1 = stream_load<SNT>(v_nm1 + off);
+    x.Tnm1 = stream_load<SNT>(T_nm1 + off);
+    x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
+    x.vn0 = stream_load<SNT>(vn0 + off);
+    x.om = stream_load<SNT>(omega_p + off);
+    x.pec = stream_load<SNT>(pecnd + off);
+    x.eta = stream_load<SNT>(eta + off);
     return x;
   };
   LevelIn cur = load_level(0);  // in flight across the barrier
@@ -319,42 +319,41 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     const double vtens2 = -ur * (fcor + vort) - gE1 - glnps2;        // P:228
     const double ttens = -vgrad_T + k.kappa * Tv[r] * om;              // P:230
 
-    double2 vo;
+    dbl2 vo;
     vo.x = spheremp * (cur.vnm1.x + k.dt2 * vtens1);                   // P:251
     vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);                   // P:252
-    v_np1[off] = vo;
-    T_np1[off] = spheremp * (cur.Tnm1 + k.dt2 * ttens);                // P:253
-    dp_np1[off] = spheremp * (cur.dpnm1 - k.dt2 * divdp[r]);           // P:254
-    phi_out[off] = phi;
-    omega_p[off] = cur.om + k.eta_ave_w * om;                          // P:173
-    double2 vn;
-    vn.x = cur.vn0.x + k.eta_ave_w * (ur * dpr);                   // P:117
-    vn.y = cur.vn0.y + k.eta_ave_w * (vr * dpr);                   // P:118
-    vn0[off] = vn;
-    eta[off] = cur.eta + eta_zero;                                     // P:172
+    stream_store<SNT>(v_np1 + off, vo);
+    stream_store<SNT>(T_np1 + off, spheremp * (cur.Tnm1 + k.dt2 * ttens));       // P:253
+    stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * divdp[r]));  // P:254
+    stream_store<SNT>(phi_out + off, phi);
+    stream_store<SNT>(omega_p + off, cur.om + k.eta_ave_w * om);                 // P:173
+    dbl2 vn;
+    vn.x = cur.vn0.x + k.eta_ave_w * (ur * dpr);                       // P:117
+    vn.y = cur.vn0.y + k.eta_ave_w * (vr * dpr);                       // P:118
+    stream_store<SNT>(vn0 + off, vn);
+    stream_store<SNT>(eta + off, cur.eta + eta_zero);                   // P:172
     cur = nxt;
     __builtin_amdgcn_sched_barrier(0);
   }
   if (tid < PP) eta_last[ulane] = l_eta_last + eta_zero;               // P:181
 }
 
-template <int NLEV, int TPW, int MINW>
+template <int NLEV, int TPW, int MINW, bool NT>
 static hipError_t launch_np8(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = NLEV / TPW * 64;
   if (k.qn0 >= 0)
-    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT>), dim3(num_elems), dim3(THREADS), 0, stream, k);
   else  // dry branch (P:128-139)
-    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false, NT>), dim3(num_elems), dim3(THREADS), 0, stream, k);
   return hipGetLastError();
 }
 
 // (non-const on purpose, see caar_np4.hip)
 KernelVariant kNp8Nlev72[] = {
-    {"caar_np8_kernel<72, 9, 1, true>", "8 waves x 9 levels", launch_np8<72, 9, 1>},
-    {"caar_np8_kernel<72, 18, 1, true>", "4 waves x 18 levels (one wave per SIMD, 512 registers)", launch_np8<72, 18, 1>},
-    {"caar_np8_kernel<72, 6, 1, true>", "12 waves x 6 levels", launch_np8<72, 6, 1>},
-    {"caar_np8_kernel<72, 12, 1, true>", "6 waves x 12 levels", launch_np8<72, 12, 1>},
-    {"caar_np8_kernel<72, 8, 1, true>", "9 waves x 8 levels", launch_np8<72, 8, 1>},
+    {"caar_np8_kernel<72, 9, 1, true, true>", "8 waves x 9 levels, nt", launch_np8<72, 9, 1, true>},
+    {"caar_np8_kernel<72, 9, 1, true, false>", "8 waves x 9 levels", launch_np8<72, 9, 1, false>},
+    {"caar_np8_kernel<72, 18, 1, true, true>", "4 waves x 18 levels (one wave per SIMD, 512 registers), nt", launch_np8<72, 18, 1, true>},
+    {"caar_np8_kernel<72, 12, 1, true, true>", "6 waves x 12 levels, nt", launch_np8<72, 12, 1, true>},
 };
 int kNp8Nlev72Count = sizeof(kNp8Nlev72) / sizeof(kNp8Nlev72[0]);
 

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--variants", type=str, default="")
+    ap.add_argument("--skeletons", type=int, default=1, help="how many traffic-skeleton variants to time")
     ap.add_argument("--json", type=str, default="")
     a = ap.parse_args()
     L = tsa.library()
@@ -84,8 +85,8 @@ def main():
 
     dims, ptrs, prm = data.arrays.dims(), data.arrays.pointers(), data.params()
 
-    def skeleton():
-        return time_ms(lambda: L.check(lib.caar_traffic_skeleton(C.byref(dims), C.byref(ptrs), C.byref(prm),
+    def skeleton(sv):
+        return time_ms(lambda: L.check(lib.caar_traffic_skeleton(C.byref(dims), C.byref(ptrs), C.byref(prm), sv,
                                                                  C.c_void_p(stream.cuda_stream)), "skel"),
                        a.reps, stream)
 
@@ -93,7 +94,8 @@ def main():
     times[("copy", 8)] = []
     times[("copy", 16)] = []
     if a.np_ == 4:
-        times[("skeleton", 0)] = []
+        for sv in range(a.skeletons):
+            times[("skeleton", sv)] = []
     for _ in range(a.rounds):
         for key in list(times):
             if key[0] == "variant":
@@ -101,7 +103,7 @@ def main():
             elif key[0] == "copy":
                 times[key].append(copy(key[1]))
             else:
-                times[key].append(skeleton())
+                times[key].append(skeleton(key[1]))
     lib.caar_select_variant(a.np_, a.nlev, 0)
 
     def med(x):
@@ -123,8 +125,8 @@ def main():
             results["copy%d" % key[1]] = dict(ms=ms, gbs=gbs)
         else:
             gbs = balg * a.elems / (ms * 1e-3) / 1e9
-            print("traffic skeleton      %8.4f ms  %7.1f GB/s alg  %5.1f%% of 8TB/s" % (ms, gbs, gbs / 80.0))
-            results["skeleton"] = dict(ms=ms, gbs=gbs)
+            print("traffic skeleton %d    %8.4f ms  %7.1f GB/s alg  %5.1f%% of 8TB/s" % (key[1], ms, gbs, gbs / 80.0))
+            results["skeleton%d" % key[1]] = dict(ms=ms, gbs=gbs)
     if a.json:
         json.dump(results, open(a.json, "w"), indent=1)
 

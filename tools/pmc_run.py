@@ -39,7 +39,7 @@ for lb in (8, 16):
     torch.cuda.synchronize()
 if a.np_ == 4:
     for _ in range(3):
-        L.check(lib.caar_traffic_skeleton(C.byref(dims), C.byref(ptrs), C.byref(prm), C.c_void_p(st.cuda_stream)), "skel")
+        L.check(lib.caar_traffic_skeleton(C.byref(dims), C.byref(ptrs), C.byref(prm), 0, C.c_void_p(st.cuda_stream)), "skel")
     torch.cuda.synchronize()
     data = tsa.TestData().init_data(a.elems, a.np_, a.nlev, device=dev)
 for _ in range(5):
