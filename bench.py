@@ -135,13 +135,23 @@ def main():
         sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs MI355X GPUs (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; CAAR_BENCH_BACKEND=gloo is a rehearsal mode that lets several ranks
+    # share the GPUs that exist (used to exercise the N>1 path on a one-GPU box)
+    backend = os.environ.get("CAAR_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        sys.exit("rank %d has no GPU (%d visible)" % (local_rank, ndev))
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    reduce_dev = dev if backend == "nccl" else torch.device("cpu")
 
     # ---- this rank's slab of the global element range -------------------------------
     total_elems = args.elems_per_gpu * world
@@ -172,7 +182,7 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
 
     from tinman_sandbox_amd import sharding
-    wall_max, kernel_ms_max = sharding.max_over_ranks([wall, kernel_ms], dist, dev)
+    wall_max, kernel_ms_max = sharding.max_over_ranks([wall, kernel_ms], dist, reduce_dev)
 
     if rank == 0:
         balg = tsa.algorithmic_bytes(args.np_, args.nlev)

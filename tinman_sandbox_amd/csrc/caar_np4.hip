@@ -119,7 +119,7 @@ __device__ __forceinline__ void scan_up(double x, int lane, int sub, double& inc
 // LDS image of the element's metric terms: 13 values per GLL point
 enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, G_D = 80, G_DINV = 144, G_SIZE = 208 };
 
-template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT>
+template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, int PF>
 __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
   constexpr int PP = 16;               // GLL points per level
   constexpr int NT = NLEV / 4;         // tiles per element
@@ -153,6 +153,38 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
   const double* __restrict__ T_n0 = k.T + (ie * tl + k.n0) * BLK + wbase;
   const double* __restrict__ Qdp = k.Qdp + ((ie * k.qsize_d + 0) * 2 + (MOIST ? k.qn0 : 0)) * BLK + wbase;
 
+  // pointers of the update phase
+  const dbl2* __restrict__ v_nm1 = reinterpret_cast<const dbl2*>(k.v + (ie * tl + k.nm1) * BLK * 2) + wbase;
+  const double* __restrict__ T_nm1 = k.T + (ie * tl + k.nm1) * BLK + wbase;
+  const double* __restrict__ dp_nm1 = k.dp3d + (ie * tl + k.nm1) * BLK + wbase;
+  dbl2* __restrict__ v_np1 = reinterpret_cast<dbl2*>(k.v + (ie * tl + k.np1) * BLK * 2) + wbase;
+  double* __restrict__ T_np1 = k.T + (ie * tl + k.np1) * BLK + wbase;
+  double* __restrict__ dp_np1 = k.dp3d + (ie * tl + k.np1) * BLK + wbase;
+  dbl2* __restrict__ vn0 = reinterpret_cast<dbl2*>(k.vn0 + ie * BLK * 2) + wbase;
+  double* __restrict__ omega_p = k.omega_p + ie * BLK + wbase;
+  double* __restrict__ phi_out = k.phi + ie * BLK + wbase;
+  const double* __restrict__ pecnd = k.pecnd + ie * BLK + wbase;
+  double* __restrict__ eta = k.eta_dot_dpdn + ie * (BLK + PP) + wbase;
+  double* __restrict__ eta_last = k.eta_dot_dpdn + ie * (BLK + PP) + BLK;
+
+  // Update-phase inputs of one tile; loaded one tile ahead of their use so that only
+  // two tiles' worth of them are ever live (register budget: 2 workgroups per CU).
+  struct TileIn {
+    dbl2 vnm1, vn0;
+    double Tnm1, dpnm1, om, pec, eta;
+  };
+  auto load_tile = [&](int r) {
+    const unsigned off = r * 64 + ulane;
+    TileIn x;
+    x.vnm1 = stream_load<SNT>(v_nm1 + off);
+    x.Tnm1 = stream_load<SNT>(T_nm1 + off);
+    x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
+    x.vn0 = stream_load<SNT>(vn0 + off);
+    x.om = stream_load<SNT>(omega_p + off);
+    x.pec = stream_load<SNT>(pecnd + off);
+    x.eta = stream_load<SNT>(eta + off);
+    return x;
+  };
   // ---- phase 0: issue the n0 loads, stage Dvv + metric terms in LDS -----------------
   double dp[TPW], u[TPW], v[TPW], T[TPW], q[TPW];
 #pragma unroll
@@ -163,6 +195,14 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
     v[r] = uv.y;
     T[r] = stream_load<SNT>(T_n0 + r * 64 + ulane);
     q[r] = MOIST ? stream_load<SNT>(Qdp + r * 64 + ulane) : 0.0;
+  }
+  // PF: when the update-phase inputs (nm1 state, vn0, omega_p, pecnd, eta) are requested:
+  // 2 = here, right behind the n0 loads (all of the element's reads in flight at once),
+  // 1 = all tiles before the last barrier, 0 = one tile ahead of its use.
+  TileIn pre[PF ? TPW : 1];
+  if (PF == 2) {
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) pre[r] = load_tile(r);
   }
   if (tid < 16) s_dvv[tid] = k.Dvv[tid];
   for (int idx = tid; idx < G_SIZE; idx += THREADS) {
@@ -238,39 +278,11 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
     }
   }
 
-  // pointers of the update phase
-  const dbl2* __restrict__ v_nm1 = reinterpret_cast<const dbl2*>(k.v + (ie * tl + k.nm1) * BLK * 2) + wbase;
-  const double* __restrict__ T_nm1 = k.T + (ie * tl + k.nm1) * BLK + wbase;
-  const double* __restrict__ dp_nm1 = k.dp3d + (ie * tl + k.nm1) * BLK + wbase;
-  dbl2* __restrict__ v_np1 = reinterpret_cast<dbl2*>(k.v + (ie * tl + k.np1) * BLK * 2) + wbase;
-  double* __restrict__ T_np1 = k.T + (ie * tl + k.np1) * BLK + wbase;
-  double* __restrict__ dp_np1 = k.dp3d + (ie * tl + k.np1) * BLK + wbase;
-  dbl2* __restrict__ vn0 = reinterpret_cast<dbl2*>(k.vn0 + ie * BLK * 2) + wbase;
-  double* __restrict__ omega_p = k.omega_p + ie * BLK + wbase;
-  double* __restrict__ phi_out = k.phi + ie * BLK + wbase;
-  const double* __restrict__ pecnd = k.pecnd + ie * BLK + wbase;
-  double* __restrict__ eta = k.eta_dot_dpdn + ie * (BLK + PP) + wbase;
-  double* __restrict__ eta_last = k.eta_dot_dpdn + ie * (BLK + PP) + BLK;
-
-  // Update-phase inputs of one tile; loaded one tile ahead of their use so that only
-  // two tiles' worth of them are ever live (register budget: 2 workgroups per CU).
-  struct TileIn {
-    dbl2 vnm1, vn0;
-    double Tnm1, dpnm1, om, pec, eta;
-  };
-  auto load_tile = [&](int r) {
-    const unsigned off = r * 64 + ulane;
-    TileIn x;
-    x.vnm1 = stream_load<SNT>(v_nm1 + off);
-    x.Tnm1 = stream_load<SNT>(T_nm1 + off);
-    x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
-    x.vn0 = stream_load<SNT>(vn0 + off);
-    x.om = stream_load<SNT>(omega_p + off);
-    x.pec = stream_load<SNT>(pecnd + off);
-    x.eta = stream_load<SNT>(eta + off);
-    return x;
-  };
-  TileIn cur = load_tile(TPW - 1);  // in flight across the barrier
+  if (PF == 1) {
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) pre[r] = load_tile(r);
+  }
+  TileIn cur = PF ? pre[TPW - 1] : load_tile(TPW - 1);  // in flight across the barrier
   double l_eta_last = 0.0;
   if (tid < PP) l_eta_last = eta_last[ulane];
   __syncthreads();
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
     const int t = w * TPW + r;
     const unsigned off = r * 64 + ulane;
     TileIn nxt = cur;
-    if (r > 0) nxt = load_tile(r - 1);
+    if (r > 0) nxt = PF ? pre[r - 1] : load_tile(r - 1);
 
     const double ht = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);         // same expression as in phase 2
     const double phi = (phis + (below + ex_ht[r])) + 0.5 * ht;    // P:303,309
@@ -339,13 +351,13 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
 }
 
 // explicit instantiations + launchers --------------------------------------------------
-template <int NLEV, int TPW, int MINW, bool NT>
+template <int NLEV, int TPW, int MINW, bool NT, int PF = 0>
 static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = NLEV / 4 / TPW * 64;
   if (k.qn0 >= 0)
-    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true, NT>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true, NT, PF>), dim3(num_elems), dim3(THREADS), 0, stream, k);
   else  // dry branch (P:128-139): the Qdp block is never touched
-    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false, NT>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false, NT, PF>), dim3(num_elems), dim3(THREADS), 0, stream, k);
   return hipGetLastError();
 }
 
@@ -355,19 +367,21 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
-    {"caar_np4_kernel<72, 2, 1, true, true>", "9 waves x 2 tiles, nt", launch_np4<72, 2, 1, true>},
-    {"caar_np4_kernel<72, 2, 1, true, false>", "9 waves x 2 tiles", launch_np4<72, 2, 1, false>},
-    {"caar_np4_kernel<72, 3, 3, true, true>", "6 waves x 3 tiles, <=168 VGPR: 2 workgroups/CU, nt", launch_np4<72, 3, 3, true>},
-    {"caar_np4_kernel<72, 3, 1, true, true>", "6 waves x 3 tiles, nt", launch_np4<72, 3, 1, true>},
-    {"caar_np4_kernel<72, 6, 1, true, true>", "3 waves x 6 tiles, nt", launch_np4<72, 6, 1, true>},
+    {"caar_np4_kernel<72, 2, 1, true, true, 1>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1>},
+    {"caar_np4_kernel<72, 2, 1, true, true, 0>", "9 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<72, 2, 1, true, 0>},
+    {"caar_np4_kernel<72, 2, 1, true, false, 1>", "9 waves x 2 tiles, default cache policy", launch_np4<72, 2, 1, false, 1>},
+    {"caar_np4_kernel<72, 3, 2, true, true, 1>", "6 waves x 3 tiles, nt, update loads before the last barrier", launch_np4<72, 3, 2, true, 1>},
+    {"caar_np4_kernel<72, 3, 3, true, true, 0>", "6 waves x 3 tiles, <=168 VGPR: 2 workgroups/CU, nt", launch_np4<72, 3, 3, true, 0>},
+    {"caar_np4_kernel<72, 6, 1, true, true, 0>", "3 waves x 6 tiles, nt", launch_np4<72, 6, 1, true, 0>},
 };
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
-    {"caar_np4_kernel<128, 4, 2, true, true>", "8 waves x 4 tiles, nt", launch_np4<128, 4, 2, true>},
-    {"caar_np4_kernel<128, 4, 2, true, false>", "8 waves x 4 tiles", launch_np4<128, 4, 2, false>},
-    {"caar_np4_kernel<128, 2, 1, true, true>", "16 waves x 2 tiles, nt", launch_np4<128, 2, 1, true>},
-    {"caar_np4_kernel<128, 8, 1, true, true>", "4 waves x 8 tiles, nt", launch_np4<128, 8, 1, true>},
+    {"caar_np4_kernel<128, 4, 2, true, true, 1>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1>},
+    {"caar_np4_kernel<128, 4, 2, true, true, 0>", "8 waves x 4 tiles, nt, update loads one tile ahead", launch_np4<128, 4, 2, true, 0>},
+    {"caar_np4_kernel<128, 4, 2, true, false, 1>", "8 waves x 4 tiles, default cache policy", launch_np4<128, 4, 2, false, 1>},
+    {"caar_np4_kernel<128, 2, 2, true, true, 1>", "16 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<128, 2, 2, true, 1>},
+    {"caar_np4_kernel<128, 8, 1, true, true, 0>", "4 waves x 8 tiles, nt", launch_np4<128, 8, 1, true, 0>},
 };
 int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 
