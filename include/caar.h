@@ -130,6 +130,22 @@ int caar_num_variants(int np, int nlev);
 int caar_select_variant(int np, int nlev, int variant);
 const char *caar_variant_info(int np, int nlev, int variant);
 
+/* ---- Fortran-layout ingest / egress -----------------------------------------------
+ * A Fortran host holds the same 16 arrays with the FIRST index fastest
+ * (fortran/element_state_mod.F90:17-23, element_mod.F90:69-121), flattened over elements:
+ *     v(np,np,2,nlev,timelevels,ne)  T,dp3d(np,np,nlev,timelevels,ne)  Qdp(np,np,nlev,qsize_d,2,ne)
+ *     phi,omega_p,pecnd(np,np,nlev,ne)  vn0(np,np,2,nlev,ne)  eta_dot_dpdn(np,np,nlev+1,ne)
+ *     D,Dinv(np,np,2,2,ne)  fcor,spheremp,metdet,rmetdet,phis(np,np,ne)
+ * (cf. the pull/push functions of level_vectorized_ppscan/Elements.cpp:154-435).
+ * `f90_dev` holds DEVICE pointers to such arrays, in the CaarArrays member order;
+ * these calls convert elements [e0, e1) to / from the C++ layout used by caar_launch.
+ * caar_layout_to_f90 with all_arrays == 0 converts only the seven arrays the path
+ * mutates.  Asynchronous on `stream`; source and destination must not overlap. */
+int caar_layout_from_f90(const CaarDims *dims, const CaarArrays *f90_dev, const CaarArrays *caar_dev,
+                         int e0, int e1, void *stream);
+int caar_layout_to_f90(const CaarDims *dims, const CaarArrays *caar_dev, const CaarArrays *f90_dev,
+                       int e0, int e1, int all_arrays, void *stream);
+
 /* ---- measurement utilities (roofline context; never on the product path) ---------
  * caar_stream_copy: device copy of n_doubles with 8 or 16 bytes per lane — the measured
  * HBM ceiling next to the spec peak and the calibration run for the HBM PMC counters.

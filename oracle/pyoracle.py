@@ -249,15 +249,18 @@ class Reference:
         return self.lib.ref_compute_norm(_ptr(f), f.size)
 
 
-def run_fortran_driver(arrs, Dvv, sc):
+def run_fortran_driver(arrs, Dvv, sc, native=False):
     """Run oracle/_ref/fortran_driver (reference Fortran routine_mod, NP=4 NLEV=72,
     physical constants fixed by physical_constants.F90) on `arrs`; returns the
-    mutated arrays.  `arrs` itself is left untouched."""
+    mutated arrays.  `arrs` itself is left untouched.  native=True returns instead a
+    dict with "c_<name>" (C++ layout, via the driver's explicit index loops) and
+    "f_<name>" (the same array in Fortran's native element order, shaped as a C-ordered
+    array with the Fortran first index last) for the layout-kernel fixtures."""
     import tempfile
     exe = os.path.join(HERE, "_ref", "fortran_driver")
-    ne = arrs["elem_state_dp3d"].shape[0]
+    ne, tl, nlev, np_, _ = arrs["elem_state_dp3d"].shape
     with tempfile.TemporaryDirectory() as td:
-        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        fin, fout, fnat = os.path.join(td, "in.bin"), os.path.join(td, "out.bin"), os.path.join(td, "nat.bin")
         with open(fin, "wb") as f:
             np.array([ne, sc["n0"], sc["np1"], sc["nm1"], sc["qn0"]], dtype=np.int32).tofile(f)
             np.array([sc["dt2"], sc["eta_ave_w"], sc["ps0"]], dtype=np.float64).tofile(f)
@@ -265,11 +268,26 @@ def run_fortran_driver(arrs, Dvv, sc):
             np.ascontiguousarray(Dvv, dtype=np.float64).tofile(f)
             for n in ARRAY_NAMES:
                 arrs[n].tofile(f)
-        subprocess.run([exe, fin, fout], check=True)
+        subprocess.run([exe, fin, fout] + ([fnat] if native else []), check=True)
         out = {}
+        names = ("elem_state_dp3d", "elem_state_v", "elem_state_T", "elem_derived_eta_dot_dpdn",
+                 "elem_derived_omega_p", "elem_derived_phi", "elem_derived_vn0")
         with open(fout, "rb") as f:
-            for n in ("elem_state_dp3d", "elem_state_v", "elem_state_T",
-                      "elem_derived_eta_dot_dpdn", "elem_derived_omega_p",
-                      "elem_derived_phi", "elem_derived_vn0"):
+            for n in names:
                 out[n] = np.fromfile(f, dtype=np.float64, count=arrs[n].size).reshape(arrs[n].shape)
-    return out
+        if not native:
+            return out
+        res = {"c_" + n: out[n] for n in names}
+        fshape = {
+            "elem_state_dp3d": (ne, tl, nlev, np_, np_), "elem_state_v": (ne, tl, nlev, 2, np_, np_),
+            "elem_state_T": (ne, tl, nlev, np_, np_), "elem_derived_eta_dot_dpdn": (ne, nlev + 1, np_, np_),
+            "elem_derived_omega_p": (ne, nlev, np_, np_), "elem_derived_phi": (ne, nlev, np_, np_),
+            "elem_derived_vn0": (ne, nlev, 2, np_, np_), "elem_state_Qdp": (ne, 2, 1, nlev, np_, np_),
+            "elem_D": (ne, 2, 2, np_, np_), "elem_fcor": (ne, np_, np_)}
+        with open(fnat, "rb") as f:
+            for n in names + ("elem_state_Qdp", "elem_D", "elem_fcor"):
+                cnt = int(np.prod(fshape[n]))
+                res["f_" + n] = np.fromfile(f, dtype=np.float64, count=cnt).reshape(fshape[n])
+        for n in ("elem_state_Qdp", "elem_D", "elem_fcor"):
+            res["c_" + n] = arrs[n].copy()
+    return res

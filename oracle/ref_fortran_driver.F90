@@ -14,6 +14,10 @@
 !   then the 16 arrays of Homme::Arrays (cxx/pointers_only/data_structures.hpp:18-44)
 !   in that order and in the C++ element-major layout.
 ! Output: state_dp3d, state_v, state_T, eta_dot_dpdn, omega_p, phi, vn0 (C++ layout).
+! Optional third argument: a second output file that receives the same seven arrays plus
+! Qdp, D, fcor in the reference's NATIVE Fortran array-element order, element by element
+! (write(u) elem(ie)%state%v ...), i.e. the flat arrays v(np,np,2,nlev,timelevels,nelemd)
+! etc. a Fortran host would hand over — the pin for the layout kernels (csrc/caar_layout.hip).
 !
 ! Index map (SURVEY.md 8a): C++ [ie][..][a][b] == Fortran elem(ie+1)%..(a+1,b+1,..).
 program ref_fortran_driver
@@ -35,10 +39,12 @@ program ref_fortran_driver
   real (kind=real_kind), allocatable :: b(:)
   integer :: ie, a, bb, c, r, k, t, q, u
   integer(kind=8) :: o
-  character(len=512) :: fin, fout
+  character(len=512) :: fin, fout, fnative
 
   call get_command_argument(1, fin)
   call get_command_argument(2, fout)
+  fnative = ''
+  if (command_argument_count() >= 3) call get_command_argument(3, fnative)
   open(newunit=u, file=trim(fin), access='stream', form='unformatted', status='old')
   read(u) hdr
   ne = hdr(1); c_n0 = hdr(2); c_np1 = hdr(3); c_nm1 = hdr(4); c_qn0 = hdr(5)
@@ -197,4 +203,38 @@ program ref_fortran_driver
   write(u) b
   deallocate(b)
   close(u)
+  if (len_trim(fnative) > 0) then
+    open(newunit=u, file=trim(fnative), access='stream', form='unformatted', status='replace')
+    do ie = 1, ne
+      write(u) elem(ie)%state%dp3d
+    end do
+    do ie = 1, ne
+      write(u) elem(ie)%state%v
+    end do
+    do ie = 1, ne
+      write(u) elem(ie)%state%T
+    end do
+    do ie = 1, ne
+      write(u) elem(ie)%derived%eta_dot_dpdn
+    end do
+    do ie = 1, ne
+      write(u) elem(ie)%derived%omega_p
+    end do
+    do ie = 1, ne
+      write(u) elem(ie)%derived%phi
+    end do
+    do ie = 1, ne
+      write(u) elem(ie)%derived%vn0
+    end do
+    do ie = 1, ne
+      write(u) elem(ie)%state%Qdp(:,:,:,:,1:2)
+    end do
+    do ie = 1, ne
+      write(u) elem(ie)%D
+    end do
+    do ie = 1, ne
+      write(u) elem(ie)%fcor
+    end do
+    close(u)
+  end if
 end program ref_fortran_driver

@@ -11,6 +11,10 @@ Produces
                                   key prefix "f90_" = the same from the reference
                                   Fortran routine (oracle/_ref/fortran_driver) where
                                   that build applies (NP=4, NLEV=72, default constants)
+  f90_native_np4_nlev72_hashed.npz  the reference Fortran routine's arrays after one call, written
+                                  in Fortran's own array-element order (write(u) elem(ie)%state%v ...)
+                                  by oracle/_ref/fortran_driver: keys "c_<name>" = C++-layout result,
+                                  "f_<name>" = the same array as Fortran stores it
   fortran_test_mod_vectors.npz    Ttest / v1test / v2test, the reference's own golden
                                   vectors, parsed as numbers from
                                   compute_and_apply_rhs_test/fortran/test_mod.F90:8-882
@@ -81,6 +85,15 @@ def main():
         np.savez_compressed(cases.golden_path(name), **out)
         print("wrote", name, {k: v.shape for k, v in out.items() if not k.startswith("f90_")},
               "+f90" if fortran_ok else "")
+
+    # Fortran-native array order (pin for the layout kernels): the hashed case, first 2 elements
+    arrs, Dvv, sc = cases.make_case("np4_nlev72_hashed")
+    scf = dict(sc)
+    scf["nets"], scf["nete"] = 0, None
+    native = po.run_fortran_driver(arrs, Dvv, scf, native=True)
+    np.savez_compressed(os.path.join(HERE, "f90_native_np4_nlev72_hashed.npz"),
+                        **{k: v[:2] for k, v in native.items()})
+    print("wrote f90_native_np4_nlev72_hashed.npz", {k: v[:2].shape for k, v in native.items()})
 
     np.savez_compressed(os.path.join(HERE, "fortran_test_mod_vectors.npz"), **parse_test_mod())
     res = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "fortran_orig")],

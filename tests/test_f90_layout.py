@@ -1,0 +1,116 @@
+"""Fortran-layout ingest/egress.
+
+Pin: tests/golden/f90_native_np4_nlev72_hashed.npz holds arrays written by the REFERENCE
+Fortran program in its own array-element order ("f_<name>", write(u) elem(ie)%state%v ...)
+next to the same arrays in the C++ layout ("c_<name>").  The host-side axis map
+(tinman_sandbox_amd/f90_layout.py) must turn one into the other exactly; the device
+kernels (csrc/caar_layout.hip) are then checked against that map, bit for bit, for every
+array, both directions, NP=4 and NP=8, qsize_d 1 and 2 (the only case that also permutes
+outer indices)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import pyoracle as po
+
+import tinman_sandbox_amd as tsa
+from tinman_sandbox_amd import f90_layout as fl
+
+
+def load_native():
+    with np.load(os.path.join(cases.GOLDEN_DIR, "f90_native_np4_nlev72_hashed.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_axis_map_matches_reference_fortran_order():
+    nat = load_native()
+    names = [k[2:] for k in nat if k.startswith("f_")]
+    assert len(names) == 10
+    c = {n: nat["c_" + n] for n in names}
+    f = {n: nat["f_" + n] for n in names}
+    to_f = fl.to_f90_numpy(c)
+    back = fl.from_f90_numpy(f)
+    for n in names:
+        assert to_f[n].shape == f[n].shape, n
+        assert np.array_equal(to_f[n], f[n]), n
+        assert np.array_equal(back[n], c[n]), n
+
+
+def test_f90_shapes():
+    s = fl.f90_shapes(4, 72, 1, 3, 5)
+    assert s["elem_state_v"] == (5, 3, 72, 2, 4, 4)          # v(np,np,2,nlev,timelevels,ne)
+    assert s["elem_state_Qdp"] == (5, 2, 1, 72, 4, 4)        # Qdp(np,np,nlev,qsize_d,2,ne)
+    assert s["elem_D"] == (5, 2, 2, 4, 4)                    # D(np,np,2,2,ne)
+    assert s["elem_derived_eta_dot_dpdn"] == (5, 73, 4, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("np_,nlev,qd", [(4, 72, 1), (4, 72, 2), (8, 72, 1), (4, 128, 1)])
+def test_device_kernels_match_axis_map(np_, nlev, qd):
+    ne = 3
+    arrs = cases.hashed_arrays(np_, nlev, ne, seed=21, qsize_d=qd)
+    want_f = fl.to_f90_numpy(arrs)
+    dev = tsa.ElementArrays.from_numpy(arrs, "cuda")
+    f90 = fl.F90Arrays(np_, nlev, ne, qd, 3, "cuda")
+    fl.egress(dev, f90, all_arrays=True)
+    torch.cuda.synchronize()
+    got_f = f90.to_numpy()
+    for n in tsa.ARRAY_NAMES:
+        assert np.array_equal(got_f[n], want_f[n]), n
+    # and back, into fresh arrays, for a sub-range of elements
+    dev2 = tsa.ElementArrays(np_, nlev, ne, qd, 3, "cuda")
+    fl.ingest(f90, dev2, 1, 3)
+    torch.cuda.synchronize()
+    got_c = dev2.to_numpy()
+    for n in tsa.ARRAY_NAMES:
+        assert np.array_equal(got_c[n][1:3], arrs[n][1:3]), n
+        assert not got_c[n][0].any(), n  # element 0 was outside [e0, e1)
+    # mutated-only egress leaves the read-only arrays of the destination alone
+    f2 = fl.F90Arrays(np_, nlev, ne, qd, 3, "cuda")
+    fl.egress(dev, f2, all_arrays=False)
+    torch.cuda.synchronize()
+    g2 = f2.to_numpy()
+    for n in tsa.ARRAY_NAMES:
+        if n in tsa.caar.MUTATED:
+            assert np.array_equal(g2[n], want_f[n]), n
+        else:
+            assert not g2[n].any(), n
+
+
+@pytest.mark.gpu
+def test_fortran_host_roundtrip_matches_reference_fortran():
+    """What a Fortran host does: Fortran-ordered inputs -> ingest -> compute_and_apply_rhs ->
+    egress -> Fortran-ordered outputs, compared with the arrays the reference Fortran
+    program itself holds after its own compute_and_apply_rhs (golden, native order)."""
+    nat = load_native()
+    arrs, Dvv, sc = cases.make_case("np4_nlev72_hashed")
+    sc["nets"], sc["nete"] = 0, 2
+    arrs = {k: v[:2].copy() for k, v in arrs.items()}
+    f_in = fl.F90Arrays.from_numpy(fl.to_f90_numpy(arrs), 4, 72, 2, device="cuda")
+    data = tsa.TestData.from_numpy({k: np.zeros_like(v) for k, v in arrs.items()}, Dvv, sc, device="cuda")
+    fl.ingest(f_in, data.arrays)
+    tsa.compute_and_apply_rhs(data)
+    fl.egress(data.arrays, f_in)  # mutated arrays back into the Fortran-ordered buffers
+    torch.cuda.synchronize()
+    got = f_in.to_numpy()
+    for n in tsa.caar.MUTATED:
+        want = nat["f_" + n]
+        assert cases.scaled_err(got[n], want) <= 1e-12, n
+
+
+@pytest.mark.gpu
+def test_layout_kernels_full_size_roundtrip():
+    """10 000 elements: egress then ingest is the identity (a permutation and its inverse)."""
+    data = tsa.TestData().init_data(10000, 4, 72, device="cuda")
+    f90 = fl.F90Arrays(4, 72, 10000, device="cuda")
+    back = tsa.ElementArrays(4, 72, 10000, device="cuda")
+    fl.egress(data.arrays, f90, all_arrays=True)
+    fl.ingest(f90, back)
+    torch.cuda.synchronize()
+    for n in tsa.ARRAY_NAMES:
+        assert torch.equal(back[n], data.arrays[n]), n
+    # Fortran order really differs from the C++ one (not a no-op)
+    assert not torch.equal(f90.t["elem_state_v"].flatten(), data.arrays["elem_state_v"].flatten())

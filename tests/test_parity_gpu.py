@@ -84,6 +84,28 @@ def test_hip_matches_oracle_and_golden(oracle, name):
         assert np.array_equal(got[n][nete:], arrs[n][nete:]), n
 
 
+@pytest.mark.parametrize("name", ["np4_nlev72_hashed_amplified", "np4_nlev72_closed_dry", "np4_nlev128_hashed",
+                                  "np8_nlev72_hashed"])
+def test_every_tuning_variant_matches_oracle(oracle, name):
+    """caar_select_variant: all launch shapes / cache policies compute the same thing."""
+    c = cases.CASES[name]
+    lib = tsa.library().lib
+    arrs, Dvv, sc = cases.make_case(name)
+    want = cases.copy_arrays(arrs)
+    oracle.compute_and_apply_rhs(want, Dvv, sc)
+    n = lib.caar_num_variants(c["np"], c["nlev"])
+    assert n >= 2
+    try:
+        for v in range(n):
+            assert lib.caar_select_variant(c["np"], c["nlev"], v) == 0
+            assert lib.caar_variant_info(c["np"], c["nlev"], v)
+            _, got = run_gpu(arrs, Dvv, sc)
+            check_outputs(got, want, sc, "%s/variant%d" % (name, v))
+    finally:
+        lib.caar_select_variant(c["np"], c["nlev"], 0)
+    assert lib.caar_select_variant(c["np"], c["nlev"], n) == -1
+
+
 def test_hip_matches_fortran_golden_vectors():
     """The reference's own check (fortran/main.F90:241-274) applied to the HIP result."""
     import os

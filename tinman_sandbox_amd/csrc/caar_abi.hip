@@ -26,6 +26,8 @@ hipError_t launch_state_norms(const double* v, const double* T, const double* dp
 
 hipError_t launch_stream_copy(double* dst, const double* src, size_t n_doubles, int lane_bytes,
                               hipStream_t stream);
+hipError_t launch_layout(double* dst, const double* src, size_t n, int np, int nc, int nlev, int qd,
+                         int qdp_outer, bool to_caar, hipStream_t s);
 hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t stream);
 
 struct Config {
@@ -207,6 +209,40 @@ static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const Caar
   k.Rgas = p->Rgas;
   k.kappa = p->kappa;
   k.p_top = p->hyai0 * p->ps0;  // P:84
+}
+
+// components per GLL point of array i (CaarArrays member order)
+static int array_ncomp(int i) { return (i == 0 || i == 1) ? 4 : ((i == 7 || i == 15) ? 2 : 1); }
+
+static int convert_layout(const CaarDims* d, const CaarArrays* from, const CaarArrays* to, int e0, int e1,
+                          bool to_caar, bool mutated_only, void* stream) {
+  if (!d || !from || !to || e0 < 0 || e1 > d->num_elems || e0 > e1) return CAAR_EINVAL;
+  if (d->np != 4 && d->np != 8) return CAAR_EUNSUPPORTED;
+  for (int i = 0; i < CAAR_NUM_ARRAYS; ++i) {
+    bool wanted = !mutated_only;
+    for (int m : kMutated) wanted = wanted || m == i;
+    if (!wanted) continue;
+    const double* s = *array_slot(from, i);
+    double* t = *array_slot(to, i);
+    if (!s || !t) return CAAR_EINVAL;
+    const long long per = caar_array_len(d, i) / (d->num_elems ? d->num_elems : 1);
+    // every array is element-major on both sides, so [e0, e1) is one contiguous range
+    hipError_t e = caar::launch_layout(t + (size_t)per * e0, s + (size_t)per * e0, (size_t)per * (e1 - e0),
+                                       d->np, array_ncomp(i), d->nlev, d->qsize_d, i == 10, to_caar,
+                                       (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  return CAAR_OK;
+}
+
+int caar_layout_from_f90(const CaarDims* dims, const CaarArrays* f90_dev, const CaarArrays* caar_dev, int e0,
+                         int e1, void* stream) {
+  return convert_layout(dims, f90_dev, caar_dev, e0, e1, true, false, stream);
+}
+
+int caar_layout_to_f90(const CaarDims* dims, const CaarArrays* caar_dev, const CaarArrays* f90_dev, int e0,
+                       int e1, int all_arrays, void* stream) {
+  return convert_layout(dims, caar_dev, f90_dev, e0, e1, false, !all_arrays, stream);
 }
 
 /* Measurement utilities (roofline context; not used by the product path). */
