@@ -1,0 +1,113 @@
+"""How a host uses the path beyond one call: time stepping with rotating levels, an empty
+element range, extra tracer slots, side streams and hipGraph capture."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import pyoracle as po
+
+import tinman_sandbox_amd as tsa
+
+pytestmark = pytest.mark.gpu
+
+
+def test_time_stepping_trajectory_matches_oracle(oracle):
+    """Five calls with update_time_levels between them (TestData::update_time_levels,
+    data_structures.cpp:174-180; the reference driver has the call commented out,
+    main.cpp:118, so this is the real leap-frog use).  Rounding differences feed back
+    through the state, so the bound is looser than for one call."""
+    arrs, Dvv, sc = cases.make_case("np4_nlev72_hashed")
+    sc["dt2"] = 0.5
+    ref = cases.copy_arrays(arrs)
+    data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    s = dict(sc)
+    for _ in range(5):
+        oracle.compute_and_apply_rhs(ref, Dvv, s)
+        s["np1"], s["nm1"], s["n0"] = s["nm1"], s["n0"], s["np1"]
+        tsa.compute_and_apply_rhs(data)
+        data.update_time_levels()
+    torch.cuda.synchronize()
+    assert (data.control.n0, data.control.np1, data.control.nm1) == (s["n0"], s["np1"], s["nm1"])
+    got = data.arrays.to_numpy()
+    for n in tsa.caar.MUTATED:
+        assert cases.scaled_err(got[n], ref[n]) <= 1e-11, n
+
+
+def test_empty_element_range_is_a_noop():
+    arrs, Dvv, sc = cases.make_case("np4_nlev72_closed_dry")
+    sc["nets"] = sc["nete"] = 1
+    data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    tsa.compute_and_apply_rhs(data)
+    torch.cuda.synchronize()
+    got = data.arrays.to_numpy()
+    for n in tsa.ARRAY_NAMES:
+        assert np.array_equal(got[n], arrs[n]), n
+
+
+def test_extra_tracer_slots_are_ignored(oracle):
+    """qsize_d = 3: the path reads tracer 0 only (P:143 SLICE_6D_IJK(..., ie, 0, qn0, ...))."""
+    arrs = cases.hashed_arrays(4, 72, 2, seed=31, qsize_d=3)
+    sc = po.default_scalars(72)
+    sc.update(qn0=1, dt2=3.0)
+    Dvv = cases.dvv_for(4)
+    want = cases.copy_arrays(arrs)
+    oracle.compute_and_apply_rhs(want, Dvv, sc)
+    data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    tsa.compute_and_apply_rhs(data)
+    torch.cuda.synchronize()
+    got = data.arrays.to_numpy()
+    for n in tsa.caar.MUTATED:
+        assert cases.scaled_err(got[n], want[n]) <= 1e-12, n
+    assert np.array_equal(got["elem_state_Qdp"], arrs["elem_state_Qdp"])
+
+
+def test_side_stream_and_graph_capture(oracle):
+    """caar_launch allocates nothing and never synchronises: it runs on any stream and can
+    be captured into a hipGraph and replayed."""
+    arrs, Dvv, sc = cases.make_case("np4_nlev72_closed")
+    want = cases.copy_arrays(arrs)
+    oracle.compute_and_apply_rhs(want, Dvv, sc)
+    data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    data.dvv_device()  # upload Dvv outside the capture
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        tsa.compute_and_apply_rhs(data, side)
+    side.synchronize()
+    first = data.arrays.to_numpy()
+    for n in ("elem_state_v", "elem_state_T", "elem_state_dp3d", "elem_derived_phi"):
+        assert cases.scaled_err(first[n], want[n]) <= 1e-12, n
+
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        tsa.compute_and_apply_rhs(data)  # captured on the capture stream
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    again = data.arrays.to_numpy()
+    # the np1 state is idempotent; the accumulators have now received 1 + capture(0) + 2 updates
+    for n in ("elem_state_v", "elem_state_T", "elem_state_dp3d", "elem_derived_phi"):
+        assert np.array_equal(again[n], first[n]), n
+    inc = first["elem_derived_vn0"] - arrs["elem_derived_vn0"]
+    total = again["elem_derived_vn0"] - arrs["elem_derived_vn0"]
+    assert cases.scaled_err(total, 3 * inc) <= 1e-12
+
+
+def test_single_element_and_large_offsets(oracle):
+    """One element at the far end of a long array: 64-bit offsets, last workgroup."""
+    E = 4001
+    data = tsa.TestData().init_data(E, 4, 72, device="cuda")
+    data.control.nets, data.control.nete = E - 1, E
+    before = {n: data.arrays[n].clone() for n in tsa.caar.MUTATED}
+    tsa.compute_and_apply_rhs(data)
+    torch.cuda.synchronize()
+    O = oracle
+    ref = O.init_arrays(4, 72, 1, 3, E)
+    sc = po.default_scalars(72)
+    sc["nets"], sc["nete"] = E - 1, E
+    O.compute_and_apply_rhs(ref, O.dvv_np4(False), sc)
+    for n in tsa.caar.MUTATED:
+        got = data.arrays[n].cpu().numpy()
+        assert cases.scaled_err(got[E - 1], ref[n][E - 1]) <= 1e-12, n
+        assert torch.equal(data.arrays[n][: E - 1], before[n][: E - 1]), n
