@@ -129,6 +129,10 @@ const char *caar_kernel_name(int np, int nlev);
 int caar_num_variants(int np, int nlev);
 int caar_select_variant(int np, int nlev, int variant);
 const char *caar_variant_info(int np, int nlev, int variant);
+/* Workgroup -> element mapping: 0 (default) deals consecutive elements round-robin over the
+ * XCDs (all XCDs sweep the arrays together: measured 2-4 % faster, better DRAM locality);
+ * 1 gives each XCD one contiguous eighth of the element range.  Same results either way. */
+int caar_set_xcd_chunked(int on);
 
 /* ---- Fortran-layout ingest / egress -----------------------------------------------
  * A Fortran host holds the same 16 arrays with the FIRST index fastest

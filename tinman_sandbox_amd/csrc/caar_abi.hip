@@ -57,6 +57,8 @@ static Config* find_config(int np, int nlev) {
 }
 }  // namespace caar
 
+static int g_xcd_chunked = 0;  // workgroup -> element mapping, see element_of_block()
+
 struct CaarContext {
   CaarDims dims;
   int device;
@@ -102,6 +104,11 @@ int caar_select_variant(int np, int nlev, int variant) {
   if (!c) return CAAR_EUNSUPPORTED;
   if (variant < 0 || variant >= c->count) return CAAR_EINVAL;
   c->selected = variant;
+  return CAAR_OK;
+}
+
+int caar_set_xcd_chunked(int on) {
+  g_xcd_chunked = on ? 1 : 0;
   return CAAR_OK;
 }
 
@@ -196,6 +203,8 @@ static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const Caar
   k.vn0 = dev->elem_derived_vn0;
   k.Dvv = dvv_dev;
   k.nets = p->nets;
+  k.nelem = p->nete - p->nets;
+  k.per_xcd = g_xcd_chunked ? (k.nelem + 7) / 8 : 0;
   k.n0 = p->n0;
   k.np1 = p->np1;
   k.nm1 = p->nm1;

@@ -26,7 +26,9 @@ struct KernelArgs {
   const double* pecnd;
   double* vn0;
   const double* Dvv;  // np*np, row-major Dvv[i][j]
-  int nets;           // first element of this launch; blockIdx.x counts from it
+  int nets;           // first element of this launch
+  int nelem;          // elements in this launch
+  int per_xcd;        // 0: element = nets + blockIdx.x; else XCD-chunked mapping (element_of_block)
   int n0, np1, nm1;
   int qn0;            // -1: dry
   int qsize_d, timelevels;
@@ -38,6 +40,21 @@ struct KernelArgs {
   double kappa;
   double p_top;          // hyai[0]*ps0 (P:84)
 };
+
+// Workgroup -> element.  Workgroups are dealt round-robin over the 8 XCDs
+// (blockIdx % 8 shares an XCD; MI355X_MICROARCH.md), so with the plain mapping (default)
+// the co-resident workgroups of all XCDs work on ~256 CONSECUTIVE elements: the chip
+// sweeps every array front to back.  The chunked mapping gives XCD x the contiguous
+// element range [x*per_xcd, (x+1)*per_xcd) (one eighth of the pages per L2/TLB) — it
+// measured 2-4 % SLOWER (profiles/r01/kbench_xcd_mapping.log; DRAM locality wins over
+// TLB reach), so it is kept only as a knob.  Speed only — any placement computes the
+// same thing.  Returns -1 for the padding blocks of the rounded-up grid.
+__device__ __forceinline__ long long element_of_block(const KernelArgs& k, unsigned b) {
+  if (k.per_xcd == 0) return (long long)k.nets + b;
+  const unsigned x = b & 7u, s = b >> 3;
+  const long long e = (long long)x * k.per_xcd + s;
+  return (s < (unsigned)k.per_xcd && e < k.nelem) ? k.nets + e : -1;
+}
 
 // 1/x for a normal, non-zero fp64 x: v_rcp_f64 seed + two Newton steps (5 instructions,
 // <= 1 ulp), instead of the IEEE division sequence (v_div_scale/fmas/fixup, ~12

@@ -53,7 +53,9 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64) void traffic_skeleton_np4(cons
   const int tid = threadIdx.x, lane = tid & 63, pt = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned ulane = lane;
-  const size_t ie = (size_t)k.nets + blockIdx.x, tl = (size_t)k.timelevels;
+  const long long ie_s = element_of_block(k, blockIdx.x);
+  if (ie_s < 0) return;
+  const size_t ie = (size_t)ie_s, tl = (size_t)k.timelevels;
   const size_t wb = (size_t)w * (TPW * 64);
   const double* dp_n0 = k.dp3d + (ie * tl + k.n0) * BLK + wb;
   const double* vv_n0 = k.v + ((ie * tl + k.n0) * BLK + wb) * 2;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64) void traffic_skeleton_np4(cons
 
 template <int NLEV, int TPW, bool NTL, bool NTS, bool AF>
 static void skel(const KernelArgs& k, int n, hipStream_t s) {
-  hipLaunchKernelGGL((traffic_skeleton_np4<NLEV, TPW, NTL, NTS, AF>), dim3(n), dim3(NLEV / 4 / TPW * 64), 0, s, k);
+  hipLaunchKernelGGL((traffic_skeleton_np4<NLEV, TPW, NTL, NTS, AF>), dim3(k.per_xcd ? 8 * k.per_xcd : n), dim3(NLEV / 4 / TPW * 64), 0, s, k);
 }
 
 hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t s) {

@@ -139,7 +139,9 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pt = lane & 15;
   const int sub = lane >> 4;
-  const size_t ie = (size_t)k.nets + blockIdx.x;
+  const long long ie_s = element_of_block(k, blockIdx.x);
+  if (ie_s < 0) return;  // padding block of the XCD-chunked grid (uniform for the workgroup)
+  const size_t ie = (size_t)ie_s;
   const size_t tl = (size_t)k.timelevels;
   // Addressing: every field pointer below is wave-uniform (element, time level and this
   // wave's first tile folded in: an SGPR pair) and is indexed by `r * 64 + ulane` with r
@@ -355,9 +357,9 @@ template <int NLEV, int TPW, int MINW, bool NT, int PF = 0>
 static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = NLEV / 4 / TPW * 64;
   if (k.qn0 >= 0)
-    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true, NT, PF>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true, NT, PF>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(THREADS), 0, stream, k);
   else  // dry branch (P:128-139): the Qdp block is never touched
-    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false, NT, PF>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false, NT, PF>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(THREADS), 0, stream, k);
   return hipGetLastError();
 }
 

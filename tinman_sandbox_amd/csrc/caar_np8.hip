@@ -130,7 +130,9 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pt = lane;
-  const size_t ie = (size_t)k.nets + blockIdx.x;
+  const long long ie_s = element_of_block(k, blockIdx.x);
+  if (ie_s < 0) return;  // padding block of the XCD-chunked grid (uniform for the workgroup)
+  const size_t ie = (size_t)ie_s;
   const size_t tl = (size_t)k.timelevels;
   const int lev0 = w * TPW;
   // Addressing as in caar_np4.hip: wave-uniform field pointers (element, time level and
@@ -342,9 +344,9 @@ template <int NLEV, int TPW, int MINW, bool NT>
 static hipError_t launch_np8(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = NLEV / TPW * 64;
   if (k.qn0 >= 0)
-    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(THREADS), 0, stream, k);
   else  // dry branch (P:128-139)
-    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false, NT>), dim3(num_elems), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false, NT>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(THREADS), 0, stream, k);
   return hipGetLastError();
 }
 

@@ -69,9 +69,12 @@ def main():
                 err = float((out[n] - ref[n]).abs().max() / ref[n].abs().max().clamp_min(1e-300))
                 assert err <= 1e-12, (v, n, err)
 
-    def run_variant(v):
+    def run_variant(v, chunked=0):
         L.check(lib.caar_select_variant(a.np_, a.nlev, v), "select")
-        return time_ms(lambda: tsa.compute_and_apply_rhs(data, stream), a.reps, stream)
+        lib.caar_set_xcd_chunked(chunked)
+        t = time_ms(lambda: tsa.compute_and_apply_rhs(data, stream), a.reps, stream)
+        lib.caar_set_xcd_chunked(0)
+        return t
 
     # memory ceilings
     n_copy = 1 << 28  # 2 GiB src + 2 GiB dst
@@ -91,6 +94,7 @@ def main():
                        a.reps, stream)
 
     times = {("variant", v): [] for v in which}
+    times[("roundrobin", which[0])] = []  # default variant with the XCD-chunked element mapping
     times[("copy", 8)] = []
     times[("copy", 16)] = []
     if a.np_ == 4:
@@ -100,6 +104,8 @@ def main():
         for key in list(times):
             if key[0] == "variant":
                 times[key].append(run_variant(key[1]))
+            elif key[0] == "roundrobin":
+                times[key].append(run_variant(key[1], 1))
             elif key[0] == "copy":
                 times[key].append(copy(key[1]))
             else:
@@ -119,6 +125,10 @@ def main():
             print("variant %d  %8.4f ms  %7.3f M upd/s  %7.1f GB/s alg  %5.1f%% of 8TB/s  [min %.4f max %.4f]  %s" % (
                 v, ms, a.elems / ms / 1e3, gbs, gbs / 80.0, min(ts), max(ts), name))
             results["variant%d" % v] = dict(ms=ms, gbs=gbs, what=name)
+        elif key[0] == "roundrobin":
+            gbs = balg * a.elems / (ms * 1e-3) / 1e9
+            print("variant %d XCD-chunked elements  %8.4f ms  %7.1f GB/s alg  %5.1f%% of 8TB/s" % (key[1], ms, gbs, gbs / 80.0))
+            results["variant%d_xcd_chunked" % key[1]] = dict(ms=ms, gbs=gbs)
         elif key[0] == "copy":
             gbs = 2 * n_copy * 8 / (ms * 1e-3) / 1e9
             print("stream copy %2d B/lane  %8.4f ms  %7.1f GB/s (read+write)  %5.1f%% of 8TB/s" % (key[1], ms, gbs, gbs / 80.0))
