@@ -109,10 +109,21 @@ long long caar_algorithmic_bytes(int np, int nlev, int dry);
  * layout above (e.g. torch tensors or hipMalloc'd buffers); `stream` is a
  * hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing.
  * `dvv_dev` is a DEVICE buffer of np*np doubles holding params->Dvv (the caller
- * uploads it once; params->Dvv is ignored here).  No allocation, no
+ * uploads it once; params->Dvv is ignored here).  elem_state_v and elem_derived_vn0 must
+ * be 16-byte aligned (they are moved as (u, v) pairs), the rest 8-byte.  No allocation, no
  * synchronisation, safe to capture in a hipGraph. */
 int caar_launch(const CaarDims *dims, const CaarArrays *dev, const double *dvv_dev,
                 const CaarParams *params, void *stream);
+
+/* The three sphere operators on their own (reference: sphere_operators.hpp:9-16,
+ * gradient_sphere / divergence_sphere / vorticity_sphere(field, data, ielem, out)), batched
+ * over `nlevels` fields of element `ie`.  which = 0 gradient: in [lev][np][np] -> out
+ * [lev][np][np][2]; 1 divergence, 2 vorticity: in [lev][np][np][2] -> out [lev][np][np].
+ * `dev` supplies elem_D, elem_Dinv, elem_metdet, elem_rmetdet (device); in/out are device
+ * buffers.  Runs the same device functions the fused kernel uses.  Asynchronous. */
+int caar_sphere_operator(const CaarDims *dims, const CaarArrays *dev, const double *dvv_dev, int which,
+                         int ie, int nlevels, const double *in_dev, double *out_dev, double rrearth,
+                         void *stream);
 
 /* print_results_2norm's per-element arithmetic (P:353-390) on device-resident arrays:
  * out_dev[3*(e-e0)+f] = pow(compute_norm(field_f of element e at time level tl), 2),

@@ -232,3 +232,29 @@ def test_full_size_properties():
     torch.cuda.synchronize()
     for n, t in snap.items():
         assert torch.equal(t, data.arrays[n]), n
+
+
+@pytest.mark.parametrize("np_,nlev", [(4, 72), (8, 72)])
+def test_sphere_operators_match_oracle(oracle, np_, nlev):
+    """gradient_sphere / divergence_sphere / vorticity_sphere on their own (S:9-129), driven
+    like the reference's functions: one element, a batch of level fields."""
+    ne, nl = 3, 13  # 13 levels: not a multiple of the 4 levels a wave covers at NP=4
+    arrs = cases.hashed_arrays(np_, nlev, ne, seed=41)
+    Dvv = cases.dvv_for(np_, "double" if np_ == 4 else "gll")
+    sc = po.default_scalars(nlev)
+    sc["rrearth"] = 0.37
+    data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    s = cases.uniform((nl, np_, np_), 51, -3.0, 5.0)
+    v = cases.uniform((nl, np_, np_, 2), 52, -3.0, 5.0)
+    for ie in (0, 2):
+        g = tsa.sphere_operator(0, torch.from_numpy(s).cuda(), data, ie).cpu().numpy()
+        d = tsa.sphere_operator(1, torch.from_numpy(v).cuda(), data, ie).cpu().numpy()
+        w = tsa.sphere_operator(2, torch.from_numpy(v).cuda(), data, ie).cpu().numpy()
+        for k in range(nl):
+            wg = oracle.gradient_sphere(s[k], Dvv, arrs["elem_Dinv"][ie], 0.37)
+            wd = oracle.divergence_sphere(v[k], Dvv, arrs["elem_Dinv"][ie], arrs["elem_metdet"][ie],
+                                          arrs["elem_rmetdet"][ie], 0.37)
+            ww = oracle.vorticity_sphere(v[k], Dvv, arrs["elem_D"][ie], arrs["elem_rmetdet"][ie], 0.37)
+            assert cases.scaled_err(g[k], wg) <= 1e-14, (ie, k)
+            assert cases.scaled_err(d[k], wd) <= 1e-14, (ie, k)
+            assert cases.scaled_err(w[k], ww) <= 1e-14, (ie, k)

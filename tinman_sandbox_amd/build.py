@@ -15,7 +15,7 @@ HOST = os.path.join(HERE, "host")
 LIB = os.path.join(CSRC, "libcaar_hip.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["caar_np4.hip", "caar_np8.hip", "caar_abi.hip", "caar_norms.hip", "caar_layout.hip", "caar_membench.hip"]
+HIP_SOURCES = ["caar_np4.hip", "caar_np8.hip", "caar_abi.hip", "caar_norms.hip", "caar_layout.hip", "caar_operators.hip", "caar_membench.hip"]
 
 
 def hipcc():
@@ -34,8 +34,8 @@ def _stale(target, sources):
 
 def build_library(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "caar_kernel_args.h"),
-                   os.path.join(HERE, "..", "include", "caar.h")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
+        os.path.join(HERE, "..", "include", "caar.h")]
     if force or _stale(LIB, deps):
         cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
                "-fno-gpu-rdc"] + srcs + ["-o", LIB]

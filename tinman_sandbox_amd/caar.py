@@ -58,7 +58,7 @@ class CaarLibrary:
     """ctypes view of libcaar_hip.so; every symbol of include/caar.h is bound here."""
 
     SYMBOLS = ("caar_supported", "caar_abi_version", "caar_strerror", "caar_array_len",
-               "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms",
+               "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator",
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
                "caar_variant_info", "caar_set_xcd_chunked", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_traffic_skeleton", "caar_create", "caar_destroy", "caar_upload", "caar_download",
                "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
@@ -84,6 +84,8 @@ class CaarLibrary:
                                   C.POINTER(_CaarParams), vp]
         L.caar_launch_state_norms.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays), C.c_int,
                                               C.c_int, C.c_int, vp, vp]
+        L.caar_sphere_operator.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays), vp, C.c_int, C.c_int,
+                                           C.c_int, vp, vp, C.c_double, vp]
         L.caar_kernel_name.argtypes = [C.c_int, C.c_int]
         L.caar_kernel_name.restype = C.c_char_p
         L.caar_num_variants.argtypes = [C.c_int, C.c_int]
@@ -414,6 +416,26 @@ def compute_and_apply_rhs(data, stream=None):
     rc = L.lib.caar_launch(C.byref(dims), C.byref(ptrs), C.c_void_p(data.dvv_device().data_ptr()),
                            C.byref(prm), C.c_void_p(stream.cuda_stream))
     L.check(rc, "caar_launch")
+
+
+def sphere_operator(which, field, data, ielem):
+    """gradient_sphere (which=0) / divergence_sphere (1) / vorticity_sphere (2) of the
+    reference (sphere_operators.hpp:9-16) applied to a batch of levels of element `ielem`:
+    `field` is a device tensor [nlevels][np][np] (gradient) or [nlevels][np][np][2]."""
+    L = library()
+    _require_gpu(data.arrays)
+    np_ = data.arrays.np
+    nl = field.shape[0]
+    f = field.contiguous()
+    want = (nl, np_, np_) if which == 0 else (nl, np_, np_, 2)
+    assert tuple(f.shape) == want and f.dtype == torch.float64
+    out = torch.empty((nl, np_, np_, 2) if which == 0 else (nl, np_, np_), dtype=torch.float64, device=f.device)
+    stream = torch.cuda.current_stream(data.arrays.device)
+    dims, ptrs = data.arrays.dims(), data.arrays.pointers()
+    L.check(L.lib.caar_sphere_operator(C.byref(dims), C.byref(ptrs), C.c_void_p(data.dvv_device().data_ptr()), which,
+                                       ielem, nl, C.c_void_p(f.data_ptr()), C.c_void_p(out.data_ptr()),
+                                       data.constants.rrearth, C.c_void_p(stream.cuda_stream)), "caar_sphere_operator")
+    return out
 
 
 def state_norms(data, tl=None):

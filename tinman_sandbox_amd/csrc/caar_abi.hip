@@ -26,6 +26,9 @@ hipError_t launch_state_norms(const double* v, const double* T, const double* dp
 
 hipError_t launch_stream_copy(double* dst, const double* src, size_t n_doubles, int lane_bytes,
                               hipStream_t stream);
+hipError_t launch_sphere_operator(int np, int which, const double* in, double* out, const double* D,
+                                  const double* Dinv, const double* metdet, const double* rmetdet,
+                                  const double* dvv, int ie, int nlevels, double rrearth, hipStream_t s);
 hipError_t launch_layout(double* dst, const double* src, size_t n, int np, int nc, int nlev, int qd,
                          int qdp_outer, bool to_caar, hipStream_t s);
 hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t stream);
@@ -173,6 +176,10 @@ int caar_launch(const CaarDims* dims, const CaarArrays* dev, const double* dvv_d
   if (!dev || !dvv_dev) return CAAR_EINVAL;
   for (int i = 0; i < CAAR_NUM_ARRAYS; ++i)
     if (!*array_slot(dev, i)) return CAAR_EINVAL;
+  // the kernels move v and vn0 as 16-byte (u, v) pairs and everything else as 8-byte doubles
+  if (((size_t)dev->elem_state_v | (size_t)dev->elem_derived_vn0) & 15) return CAAR_EINVAL;
+  for (int i = 0; i < CAAR_NUM_ARRAYS; ++i)
+    if ((size_t)*array_slot(dev, i) & 7) return CAAR_EINVAL;
   const caar::Config* cfg = caar::find_config(dims->np, dims->nlev);
   if (!cfg) return CAAR_EUNSUPPORTED;
   const int n = p->nete - p->nets;
@@ -218,6 +225,17 @@ static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const Caar
   k.Rgas = p->Rgas;
   k.kappa = p->kappa;
   k.p_top = p->hyai0 * p->ps0;  // P:84
+}
+
+int caar_sphere_operator(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev, int which, int ie,
+                         int nlevels, const double* in_dev, double* out_dev, double rrearth, void* stream) {
+  if (!dims || !dev || !dvv_dev || !in_dev || !out_dev || which < 0 || which > 2 || nlevels < 0) return CAAR_EINVAL;
+  if (ie < 0 || ie >= dims->num_elems) return CAAR_EINVAL;
+  if (dims->np != 4 && dims->np != 8) return CAAR_EUNSUPPORTED;
+  if (!dev->elem_D || !dev->elem_Dinv || !dev->elem_metdet || !dev->elem_rmetdet) return CAAR_EINVAL;
+  return (int)caar::launch_sphere_operator(dims->np, which, in_dev, out_dev, dev->elem_D, dev->elem_Dinv,
+                                           dev->elem_metdet, dev->elem_rmetdet, dvv_dev, ie, nlevels, rrearth,
+                                           (hipStream_t)stream);
 }
 
 // components per GLL point of array i (CaarArrays member order)

@@ -21,75 +21,9 @@
 #include <hip/hip_runtime.h>
 
 #include "caar_kernel_args.h"
+#include "caar_np4_ops.h"
 
 namespace caar {
-
-// ---------------------------------------------------------------- DPP helpers
-// dpp_ctrl encodings (LLVM AMDGPU): quad_perm = p0|p1<<2|p2<<4|p3<<6,
-// row_ror:n = 0x120+n.  All lanes have a valid source for these controls.
-template <int CTRL>
-__device__ __forceinline__ double dpp(double x) {
-  return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, true);
-}
-template <int CTRL>
-__device__ __forceinline__ int dppi(int x) {
-  return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, true);
-}
-
-// Per-lane slices of Dvv for lane (a, b) of a 16-lane row:
-//   ca[r] = Dvv[k_r][a] where k_r is the `a` index of the lane that row_ror:(4r)
-//           delivers to this lane (found by rotating the lane id itself, so the
-//           code does not depend on the rotate direction),
-//   cb[k] = Dvv[k][b].
-struct RowCoef {
-  double ca[4];
-  double cb[4];
-};
-
-// sum_k Dvv[k][a] f[k][b]   (derivative along the first GLL index; S:30,81,121)
-__device__ __forceinline__ double d_da(const RowCoef& c, double f) {
-  double s = c.ca[0] * f;
-  s += c.ca[1] * dpp<0x124>(f);
-  s += c.ca[2] * dpp<0x128>(f);
-  s += c.ca[3] * dpp<0x12C>(f);
-  return s;
-}
-// sum_k Dvv[k][b] f[a][k]   (derivative along the second GLL index; S:31,82,122)
-__device__ __forceinline__ double d_db(const RowCoef& c, double f) {
-  double s = c.cb[0] * dpp<0x00>(f);
-  s += c.cb[1] * dpp<0x55>(f);
-  s += c.cb[2] * dpp<0xAA>(f);
-  s += c.cb[3] * dpp<0xFF>(f);
-  return s;
-}
-
-// Metric 2x2 of this lane's point, row-major m[r][c] -> {m00, m01, m10, m11}.
-struct M22 {
-  double m00, m01, m10, m11;
-};
-
-// gradient_sphere, S:9-48
-__device__ __forceinline__ void gradient_sphere(const RowCoef& c, const M22& Dinv, double rrearth,
-                                                double s, double& g0, double& g1) {
-  const double v1 = d_da(c, s) * rrearth;
-  const double v2 = d_db(c, s) * rrearth;
-  g0 = Dinv.m00 * v1 + Dinv.m10 * v2;
-  g1 = Dinv.m01 * v1 + Dinv.m11 * v2;
-}
-// divergence_sphere, S:50-89
-__device__ __forceinline__ double divergence_sphere(const RowCoef& c, const M22& Dinv, double metdet,
-                                                    double rmetdet, double rrearth, double u, double v) {
-  const double gv0 = metdet * (Dinv.m00 * u + Dinv.m01 * v);
-  const double gv1 = metdet * (Dinv.m10 * u + Dinv.m11 * v);
-  return (d_da(c, gv0) + d_db(c, gv1)) * rmetdet * rrearth;
-}
-// vorticity_sphere, S:91-129
-__device__ __forceinline__ double vorticity_sphere(const RowCoef& c, const M22& D, double rmetdet,
-                                                   double rrearth, double u, double v) {
-  const double vc0 = D.m00 * u + D.m10 * v;
-  const double vc1 = D.m01 * u + D.m11 * v;
-  return (d_da(c, vc1) - d_db(c, vc0)) * rmetdet * rrearth;
-}
 
 // ------------------------------------------------- in-wave scans over the 4 sub-levels
 // Lanes l, l+16, l+32, l+48 hold levels 4t..4t+3 of one GLL point.
@@ -119,7 +53,10 @@ __device__ __forceinline__ void scan_up(double x, int lane, int sub, double& inc
 // LDS image of the element's metric terms: 13 values per GLL point
 enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, G_D = 80, G_DINV = 144, G_SIZE = 208 };
 
-template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, int PF>
+// PERSIST: the workgroup walks elements blockIdx.x, blockIdx.x + gridDim.x, ... and requests the
+// next element's n0 inputs while it computes the last phase of the current one, so neither the
+// workgroup launch nor the first HBM round trip of an element is exposed (one workgroup per CU).
+template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, int PF, bool PERSIST>
 __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
   constexpr int PP = 16;               // GLL points per level
   constexpr int NT = NLEV / 4;         // tiles per element
@@ -129,7 +66,7 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
   static_assert(NLEV % 4 == 0 && NT % TPW == 0, "tile decomposition");
 
   __shared__ double s_dvv[16];
-  __shared__ double s_geo[G_SIZE];
+  __shared__ double s_geo_buf[PERSIST ? 2 : 1][G_SIZE];  // double-buffered across elements
   __shared__ double s_tot_dp[NT * PP];   // sum of dp over each tile
   __shared__ double s_tot_div[NT * PP];  // sum of divdp over each tile
   __shared__ double s_tot_ht[NT * PP];   // sum of Rgas*T_v*dp/p over each tile
@@ -139,9 +76,6 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pt = lane & 15;
   const int sub = lane >> 4;
-  const long long ie_s = element_of_block(k, blockIdx.x);
-  if (ie_s < 0) return;  // padding block of the XCD-chunked grid (uniform for the workgroup)
-  const size_t ie = (size_t)ie_s;
   const size_t tl = (size_t)k.timelevels;
   // Addressing: every field pointer below is wave-uniform (element, time level and this
   // wave's first tile folded in: an SGPR pair) and is indexed by `r * 64 + ulane` with r
@@ -150,216 +84,270 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
   const unsigned ulane = lane;
   const size_t wbase = (size_t)w * (TPW * 64);  // first point of this wave's tiles inside a field block
 
-  const double* __restrict__ dp_n0 = k.dp3d + (ie * tl + k.n0) * BLK + wbase;
-  const dbl2* __restrict__ v_n0 = reinterpret_cast<const dbl2*>(k.v + (ie * tl + k.n0) * BLK * 2) + wbase;
-  const double* __restrict__ T_n0 = k.T + (ie * tl + k.n0) * BLK + wbase;
-  const double* __restrict__ Qdp = k.Qdp + ((ie * k.qsize_d + 0) * 2 + (MOIST ? k.qn0 : 0)) * BLK + wbase;
+  long long ie_s = PERSIST ? (blockIdx.x < (unsigned)k.nelem ? (long long)k.nets + blockIdx.x : -1)
+                           : element_of_block(k, blockIdx.x);
+  if (ie_s < 0) return;  // padding block (uniform for the workgroup)
+  unsigned eb = blockIdx.x;  // PERSIST: element counter relative to nets
 
-  // pointers of the update phase
-  const dbl2* __restrict__ v_nm1 = reinterpret_cast<const dbl2*>(k.v + (ie * tl + k.nm1) * BLK * 2) + wbase;
-  const double* __restrict__ T_nm1 = k.T + (ie * tl + k.nm1) * BLK + wbase;
-  const double* __restrict__ dp_nm1 = k.dp3d + (ie * tl + k.nm1) * BLK + wbase;
-  dbl2* __restrict__ v_np1 = reinterpret_cast<dbl2*>(k.v + (ie * tl + k.np1) * BLK * 2) + wbase;
-  double* __restrict__ T_np1 = k.T + (ie * tl + k.np1) * BLK + wbase;
-  double* __restrict__ dp_np1 = k.dp3d + (ie * tl + k.np1) * BLK + wbase;
-  dbl2* __restrict__ vn0 = reinterpret_cast<dbl2*>(k.vn0 + ie * BLK * 2) + wbase;
-  double* __restrict__ omega_p = k.omega_p + ie * BLK + wbase;
-  double* __restrict__ phi_out = k.phi + ie * BLK + wbase;
-  const double* __restrict__ pecnd = k.pecnd + ie * BLK + wbase;
-  double* __restrict__ eta = k.eta_dot_dpdn + ie * (BLK + PP) + wbase;
-  double* __restrict__ eta_last = k.eta_dot_dpdn + ie * (BLK + PP) + BLK;
-
-  // Update-phase inputs of one tile; loaded one tile ahead of their use so that only
-  // two tiles' worth of them are ever live (register budget: 2 workgroups per CU).
-  struct TileIn {
-    dbl2 vnm1, vn0;
-    double Tnm1, dpnm1, om, pec, eta;
+  // n0 inputs of this wave's tiles
+  struct N0In {
+    double dp[TPW], u[TPW], v[TPW], T[TPW], q[TPW];
   };
-  auto load_tile = [&](int r) {
-    const unsigned off = r * 64 + ulane;
-    TileIn x;
-    x.vnm1 = stream_load<SNT>(v_nm1 + off);
-    x.Tnm1 = stream_load<SNT>(T_nm1 + off);
-    x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
-    x.vn0 = stream_load<SNT>(vn0 + off);
-    x.om = stream_load<SNT>(omega_p + off);
-    x.pec = stream_load<SNT>(pecnd + off);
-    x.eta = stream_load<SNT>(eta + off);
+  auto load_n0 = [&](size_t ie) {
+    const double* __restrict__ dp_n0 = k.dp3d + (ie * tl + k.n0) * BLK + wbase;
+    const dbl2* __restrict__ v_n0 = reinterpret_cast<const dbl2*>(k.v + (ie * tl + k.n0) * BLK * 2) + wbase;
+    const double* __restrict__ T_n0 = k.T + (ie * tl + k.n0) * BLK + wbase;
+    const double* __restrict__ Qdp = k.Qdp + ((ie * k.qsize_d + 0) * 2 + (MOIST ? k.qn0 : 0)) * BLK + wbase;
+    N0In x;
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) {
+      x.dp[r] = stream_load<SNT>(dp_n0 + r * 64 + ulane);
+      const dbl2 uv = stream_load<SNT>(v_n0 + r * 64 + ulane);
+      x.u[r] = uv.x;
+      x.v[r] = uv.y;
+      x.T[r] = stream_load<SNT>(T_n0 + r * 64 + ulane);
+      x.q[r] = MOIST ? stream_load<SNT>(Qdp + r * 64 + ulane) : 0.0;
+    }
     return x;
   };
-  // ---- phase 0: issue the n0 loads, stage Dvv + metric terms in LDS -----------------
-  double dp[TPW], u[TPW], v[TPW], T[TPW], q[TPW];
-#pragma unroll
-  for (int r = 0; r < TPW; ++r) {
-    dp[r] = stream_load<SNT>(dp_n0 + r * 64 + ulane);
-    const dbl2 uv = stream_load<SNT>(v_n0 + r * 64 + ulane);
-    u[r] = uv.x;
-    v[r] = uv.y;
-    T[r] = stream_load<SNT>(T_n0 + r * 64 + ulane);
-    q[r] = MOIST ? stream_load<SNT>(Qdp + r * 64 + ulane) : 0.0;
-  }
-  // PF: when the update-phase inputs (nm1 state, vn0, omega_p, pecnd, eta) are requested:
-  // 2 = here, right behind the n0 loads (all of the element's reads in flight at once),
-  // 1 = all tiles before the last barrier, 0 = one tile ahead of its use.
-  TileIn pre[PF ? TPW : 1];
-  if (PF == 2) {
-#pragma unroll
-    for (int r = 0; r < TPW; ++r) pre[r] = load_tile(r);
-  }
+
+  // ---- phase 0: issue the n0 loads of the first element --------------------------------
+  N0In in = load_n0((size_t)ie_s);
   if (tid < 16) s_dvv[tid] = k.Dvv[tid];
-  for (int idx = tid; idx < G_SIZE; idx += THREADS) {
-    const double* src;
-    if (idx < G_SPHEREMP) src = k.fcor + ie * PP + idx;
-    else if (idx < G_METDET) src = k.spheremp + ie * PP + (idx - G_SPHEREMP);
-    else if (idx < G_RMETDET) src = k.metdet + ie * PP + (idx - G_METDET);
-    else if (idx < G_PHIS) src = k.rmetdet + ie * PP + (idx - G_RMETDET);
-    else if (idx < G_D) src = k.phis + ie * PP + (idx - G_PHIS);
-    else if (idx < G_DINV) src = k.D + ie * PP * 4 + (idx - G_D);
-    else src = k.Dinv + ie * PP * 4 + (idx - G_DINV);
-    s_geo[idx] = *src;
-  }
-  __syncthreads();
-
   RowCoef c;
-  {
-    const int a = pt >> 2, b = pt & 3;
-    const int s1 = dppi<0x124>(lane), s2 = dppi<0x128>(lane), s3 = dppi<0x12C>(lane);
-    c.ca[0] = s_dvv[a * 4 + a];
-    c.ca[1] = s_dvv[((s1 >> 2) & 3) * 4 + a];
-    c.ca[2] = s_dvv[((s2 >> 2) & 3) * 4 + a];
-    c.ca[3] = s_dvv[((s3 >> 2) & 3) * 4 + a];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) c.cb[kk] = s_dvv[kk * 4 + b];
-  }
-  M22 Dinv;
-  Dinv.m00 = s_geo[G_DINV + pt * 4 + 0];
-  Dinv.m01 = s_geo[G_DINV + pt * 4 + 1];
-  Dinv.m10 = s_geo[G_DINV + pt * 4 + 2];
-  Dinv.m11 = s_geo[G_DINV + pt * 4 + 3];
-  const double metdet = s_geo[G_METDET + pt];
-  const double rmetdet = s_geo[G_RMETDET + pt];
-  const double rrearth = k.rrearth;
+  int par = 0;
+  bool first = true;
 
-  // ---- phase 1: divdp, T_v, in-tile scans of dp and divdp ---------------------------
-  double divdp[TPW], Tv[TPW], ex_dp[TPW], ex_div[TPW];
-#pragma unroll
-  for (int r = 0; r < TPW; ++r) {
-    const int t = w * TPW + r;
-    divdp[r] = divergence_sphere(c, Dinv, metdet, rmetdet, rrearth, u[r] * dp[r], v[r] * dp[r]);  // P:114-121
-    Tv[r] = MOIST ? T[r] * (1.0 + k.rv_over_rd_m1 * (q[r] * recip(dp[r]))) : T[r];                       // P:135,150-151
-    double in_dp, in_div;
-    scan_down(dp[r], lane, sub, in_dp, ex_dp[r]);
-    scan_down(divdp[r], lane, sub, in_div, ex_div[r]);
-    if (sub == 3) {
-      s_tot_dp[t * PP + pt] = in_dp;
-      s_tot_div[t * PP + pt] = in_div;
-    }
-  }
-  __syncthreads();
+  for (;;) {
+    const size_t ie = (size_t)ie_s;
+    double* const s_geo = s_geo_buf[PERSIST ? par : 0];
+    double (&dp)[TPW] = in.dp;
+    double (&u)[TPW] = in.u;
+    double (&v)[TPW] = in.v;
+    double (&T)[TPW] = in.T;
+    double (&q)[TPW] = in.q;
 
-  // ---- phase 2: p, running divdp sum, hydrostatic increments and their in-tile scan --
-  double p[TPW], rp[TPW], suml[TPW], ex_ht[TPW];
-  {
-    double base_dp = 0.0, base_div = 0.0;
-    for (int t2 = 0; t2 < w * TPW; ++t2) {  // tiles above this wave's first tile (wave-uniform trip count)
-      base_dp += s_tot_dp[t2 * PP + pt];
-      base_div += s_tot_div[t2 * PP + pt];
+    // pointers of the update phase
+    const dbl2* __restrict__ v_nm1 = reinterpret_cast<const dbl2*>(k.v + (ie * tl + k.nm1) * BLK * 2) + wbase;
+    const double* __restrict__ T_nm1 = k.T + (ie * tl + k.nm1) * BLK + wbase;
+    const double* __restrict__ dp_nm1 = k.dp3d + (ie * tl + k.nm1) * BLK + wbase;
+    dbl2* __restrict__ v_np1 = reinterpret_cast<dbl2*>(k.v + (ie * tl + k.np1) * BLK * 2) + wbase;
+    double* __restrict__ T_np1 = k.T + (ie * tl + k.np1) * BLK + wbase;
+    double* __restrict__ dp_np1 = k.dp3d + (ie * tl + k.np1) * BLK + wbase;
+    dbl2* __restrict__ vn0 = reinterpret_cast<dbl2*>(k.vn0 + ie * BLK * 2) + wbase;
+    double* __restrict__ omega_p = k.omega_p + ie * BLK + wbase;
+    double* __restrict__ phi_out = k.phi + ie * BLK + wbase;
+    const double* __restrict__ pecnd = k.pecnd + ie * BLK + wbase;
+    double* __restrict__ eta = k.eta_dot_dpdn + ie * (BLK + PP) + wbase;
+    double* __restrict__ eta_last = k.eta_dot_dpdn + ie * (BLK + PP) + BLK;
+
+    // Update-phase inputs of one tile (nm1 state, vn0, omega_p, pecnd, eta).
+    struct TileIn {
+      dbl2 vnm1, vn0;
+      double Tnm1, dpnm1, om, pec, eta;
+    };
+    auto load_tile = [&](int r) {
+      const unsigned off = r * 64 + ulane;
+      TileIn x;
+      x.vnm1 = stream_load<SNT>(v_nm1 + off);
+      x.Tnm1 = stream_load<SNT>(T_nm1 + off);
+      x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
+      x.vn0 = stream_load<SNT>(vn0 + off);
+      x.om = stream_load<SNT>(omega_p + off);
+      x.pec = stream_load<SNT>(pecnd + off);
+      x.eta = stream_load<SNT>(eta + off);
+      return x;
+    };
+    // PF: when the update-phase inputs are requested: 2 = right behind the n0 loads,
+    // 1 = all tiles before the last barrier, 0 = one tile ahead of their use.
+    TileIn pre[PF ? TPW : 1];
+    if (PF == 2) {
+#pragma unroll
+      for (int r = 0; r < TPW; ++r) pre[r] = load_tile(r);
     }
+
+    // stage the element's metric terms in LDS
+    for (int idx = tid; idx < G_SIZE; idx += THREADS) {
+      const double* src;
+      if (idx < G_SPHEREMP) src = k.fcor + ie * PP + idx;
+      else if (idx < G_METDET) src = k.spheremp + ie * PP + (idx - G_SPHEREMP);
+      else if (idx < G_RMETDET) src = k.metdet + ie * PP + (idx - G_METDET);
+      else if (idx < G_PHIS) src = k.rmetdet + ie * PP + (idx - G_RMETDET);
+      else if (idx < G_D) src = k.phis + ie * PP + (idx - G_PHIS);
+      else if (idx < G_DINV) src = k.D + ie * PP * 4 + (idx - G_D);
+      else src = k.Dinv + ie * PP * 4 + (idx - G_DINV);
+      s_geo[idx] = *src;
+    }
+    __syncthreads();  // also fences the previous element's last reads of the tile totals
+
+    if (first) {
+      c = make_row_coef(s_dvv, lane);
+      first = false;
+    }
+    M22 Dinv;
+    Dinv.m00 = s_geo[G_DINV + pt * 4 + 0];
+    Dinv.m01 = s_geo[G_DINV + pt * 4 + 1];
+    Dinv.m10 = s_geo[G_DINV + pt * 4 + 2];
+    Dinv.m11 = s_geo[G_DINV + pt * 4 + 3];
+    const double metdet = s_geo[G_METDET + pt];
+    const double rmetdet = s_geo[G_RMETDET + pt];
+    const double rrearth = k.rrearth;
+
+    // ---- phase 1: divdp, T_v, in-tile scans of dp and divdp ---------------------------
+    double divdp[TPW], Tv[TPW], ex_dp[TPW], ex_div[TPW];
 #pragma unroll
     for (int r = 0; r < TPW; ++r) {
       const int t = w * TPW + r;
-      p[r] = (k.p_top + (base_dp + ex_dp[r])) + 0.5 * dp[r];  // P:84,94-96 in closed form
-      suml[r] = base_div + ex_div[r];                          // P:327,339: sum of divdp above
-      rp[r] = recip(p[r]);
-      const double ht = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);    // Rgas*T_v*hkl, hkl = dp/p (P:300-302)
-      double in_ht;
-      scan_up(ht, lane, sub, in_ht, ex_ht[r]);
-      if (sub == 0) s_tot_ht[t * PP + pt] = in_ht;
-      base_dp += s_tot_dp[t * PP + pt];
-      base_div += s_tot_div[t * PP + pt];
+      divdp[r] = divergence_sphere(c, Dinv, metdet, rmetdet, rrearth, u[r] * dp[r], v[r] * dp[r]);  // P:114-121
+      Tv[r] = MOIST ? T[r] * (1.0 + k.rv_over_rd_m1 * (q[r] * recip(dp[r]))) : T[r];               // P:135,150-151
+      double in_dp, in_div;
+      scan_down(dp[r], lane, sub, in_dp, ex_dp[r]);
+      scan_down(divdp[r], lane, sub, in_div, ex_div[r]);
+      if (sub == 3) {
+        s_tot_dp[t * PP + pt] = in_dp;
+        s_tot_div[t * PP + pt] = in_div;
+      }
     }
-  }
+    __syncthreads();
 
-  if (PF == 1) {
+    // ---- phase 2: p, running divdp sum, hydrostatic increments and their in-tile scan --
+    double p[TPW], rp[TPW], suml[TPW], ex_ht[TPW];
+    {
+      double base_dp = 0.0, base_div = 0.0;
+      for (int t2 = 0; t2 < w * TPW; ++t2) {  // tiles above this wave's first tile (wave-uniform trip count)
+        base_dp += s_tot_dp[t2 * PP + pt];
+        base_div += s_tot_div[t2 * PP + pt];
+      }
 #pragma unroll
-    for (int r = 0; r < TPW; ++r) pre[r] = load_tile(r);
-  }
-  TileIn cur = PF ? pre[TPW - 1] : load_tile(TPW - 1);  // in flight across the barrier
-  double l_eta_last = 0.0;
-  if (tid < PP) l_eta_last = eta_last[ulane];
-  __syncthreads();
+      for (int r = 0; r < TPW; ++r) {
+        const int t = w * TPW + r;
+        p[r] = (k.p_top + (base_dp + ex_dp[r])) + 0.5 * dp[r];  // P:84,94-96 in closed form
+        suml[r] = base_div + ex_div[r];                          // P:327,339: sum of divdp above
+        rp[r] = recip(p[r]);
+        const double ht = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);    // Rgas*T_v*hkl, hkl = dp/p (P:300-302)
+        double in_ht;
+        scan_up(ht, lane, sub, in_ht, ex_ht[r]);
+        if (sub == 0) s_tot_ht[t * PP + pt] = in_ht;
+        base_dp += s_tot_dp[t * PP + pt];
+        base_div += s_tot_div[t * PP + pt];
+      }
+    }
 
-  // ---- phase 3: everything else, level-local -------------------------------------------
-  M22 Dm;
-  Dm.m00 = s_geo[G_D + pt * 4 + 0];
-  Dm.m01 = s_geo[G_D + pt * 4 + 1];
-  Dm.m10 = s_geo[G_D + pt * 4 + 2];
-  Dm.m11 = s_geo[G_D + pt * 4 + 3];
-  const double fcor = s_geo[G_FCOR + pt];
-  const double spheremp = s_geo[G_SPHEREMP + pt];
-  const double phis = s_geo[G_PHIS + pt];
-  const double eta_zero = k.eta_ave_w * 0.0;  // eta_dot_dpdn_tmp == 0 (P:22,172): vertically Lagrangian
+    if (PF == 1) {
+#pragma unroll
+      for (int r = 0; r < TPW; ++r) pre[r] = load_tile(r);
+    }
+    TileIn cur = PF ? pre[TPW - 1] : load_tile(TPW - 1);  // in flight across the barrier
+    double l_eta_last = 0.0;
+    if (tid < PP) l_eta_last = eta_last[ulane];
+    __syncthreads();
 
-  double below = 0.0;  // hydrostatic sum over the tiles below this wave's last tile
-  for (int t2 = NT - 1; t2 > w * TPW + TPW - 1; --t2) below += s_tot_ht[t2 * PP + pt];
+    // PERSIST: request the next element's n0 inputs now; they land while phase 3 computes
+    N0In nxt_in;
+    long long nxt_ie = -1;
+    if (PERSIST) {
+      const unsigned eb_next = eb + gridDim.x;
+      if (eb_next < (unsigned)k.nelem) {
+        nxt_ie = (long long)k.nets + eb_next;
+        nxt_in = load_n0((size_t)nxt_ie);
+      }
+      eb = eb_next;
+    }
+
+    // ---- phase 3: everything else, level-local -------------------------------------------
+    M22 Dm;
+    Dm.m00 = s_geo[G_D + pt * 4 + 0];
+    Dm.m01 = s_geo[G_D + pt * 4 + 1];
+    Dm.m10 = s_geo[G_D + pt * 4 + 2];
+    Dm.m11 = s_geo[G_D + pt * 4 + 3];
+    const double fcor = s_geo[G_FCOR + pt];
+    const double spheremp = s_geo[G_SPHEREMP + pt];
+    const double phis = s_geo[G_PHIS + pt];
+    const double eta_zero = k.eta_ave_w * 0.0;  // eta_dot_dpdn_tmp == 0 (P:22,172): vertically Lagrangian
+
+    double below = 0.0;  // hydrostatic sum over the tiles below this wave's last tile
+    for (int t2 = NT - 1; t2 > w * TPW + TPW - 1; --t2) below += s_tot_ht[t2 * PP + pt];
 
 #pragma unroll
-  for (int rr = 0; rr < TPW; ++rr) {
-    const int r = TPW - 1 - rr;  // bottom tile of the wave first: `below` accumulates upwards
-    const int t = w * TPW + r;
-    const unsigned off = r * 64 + ulane;
-    TileIn nxt = cur;
-    if (r > 0) nxt = PF ? pre[r - 1] : load_tile(r - 1);
+    for (int rr = 0; rr < TPW; ++rr) {
+      const int r = TPW - 1 - rr;  // bottom tile of the wave first: `below` accumulates upwards
+      const int t = w * TPW + r;
+      const unsigned off = r * 64 + ulane;
+      TileIn nxt = cur;
+      if (r > 0) nxt = PF ? pre[r - 1] : load_tile(r - 1);
 
-    const double ht = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);         // same expression as in phase 2
-    const double phi = (phis + (below + ex_ht[r])) + 0.5 * ht;    // P:303,309
-    below += s_tot_ht[t * PP + pt];
+      const double ht = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);         // same expression as in phase 2
+      const double phi = (phis + (below + ex_ht[r])) + 0.5 * ht;    // P:303,309
+      below += s_tot_ht[t * PP + pt];
 
-    double gp0, gp1;
-    gradient_sphere(c, Dinv, rrearth, p[r], gp0, gp1);            // P:103
-    const double vgrad_p = u[r] * gp0 + v[r] * gp1;               // P:111
-    const double ckk = 0.5 * rp[r], ckl = rp[r];                  // P:333-334 (ckl = 2*ckk)
-    const double om = vgrad_p * rp[r] - ckl * suml[r] - ckk * divdp[r];  // P:325,336,348
-    const double vort = vorticity_sphere(c, Dm, rmetdet, rrearth, u[r], v[r]);  // P:122
+      double gp0, gp1;
+      gradient_sphere(c, Dinv, rrearth, p[r], gp0, gp1);            // P:103
+      const double vgrad_p = u[r] * gp0 + v[r] * gp1;               // P:111
+      const double ckk = 0.5 * rp[r], ckl = rp[r];                  // P:333-334 (ckl = 2*ckk)
+      const double om = vgrad_p * rp[r] - ckl * suml[r] - ckk * divdp[r];  // P:325,336,348
+      const double vort = vorticity_sphere(c, Dm, rmetdet, rrearth, u[r], v[r]);  // P:122
 
-    const double Ephi = 0.5 * (u[r] * u[r] + v[r] * v[r]) + phi + cur.pec;  // P:196
-    double gT0, gT1, gE0, gE1;
-    gradient_sphere(c, Dinv, rrearth, T[r], gT0, gT1);            // P:200
-    const double vgrad_T = u[r] * gT0 + v[r] * gT1;               // P:209
-    gradient_sphere(c, Dinv, rrearth, Ephi, gE0, gE1);            // P:213
-    const double gpterm = Tv[r] * rp[r];                          // P:219
-    const double glnps1 = k.Rgas * gpterm * gp0;                  // P:221
-    const double glnps2 = k.Rgas * gpterm * gp1;                  // P:222
-    const double vtens1 = v[r] * (fcor + vort) - gE0 - glnps1;    // P:227 (v_vadv == 0)
-    const double vtens2 = -u[r] * (fcor + vort) - gE1 - glnps2;   // P:228
-    const double ttens = -vgrad_T + k.kappa * Tv[r] * om;         // P:230 (T_vadv == 0)
+      const double Ephi = 0.5 * (u[r] * u[r] + v[r] * v[r]) + phi + cur.pec;  // P:196
+      double gT0, gT1, gE0, gE1;
+      gradient_sphere(c, Dinv, rrearth, T[r], gT0, gT1);            // P:200
+      const double vgrad_T = u[r] * gT0 + v[r] * gT1;               // P:209
+      gradient_sphere(c, Dinv, rrearth, Ephi, gE0, gE1);            // P:213
+      const double gpterm = Tv[r] * rp[r];                          // P:219
+      const double glnps1 = k.Rgas * gpterm * gp0;                  // P:221
+      const double glnps2 = k.Rgas * gpterm * gp1;                  // P:222
+      const double vtens1 = v[r] * (fcor + vort) - gE0 - glnps1;    // P:227 (v_vadv == 0)
+      const double vtens2 = -u[r] * (fcor + vort) - gE1 - glnps2;   // P:228
+      const double ttens = -vgrad_T + k.kappa * Tv[r] * om;         // P:230 (T_vadv == 0)
 
-    dbl2 vo;
-    vo.x = spheremp * (cur.vnm1.x + k.dt2 * vtens1);              // P:251
-    vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);              // P:252
-    stream_store<SNT>(v_np1 + off, vo);
-    stream_store<SNT>(T_np1 + off, spheremp * (cur.Tnm1 + k.dt2 * ttens));        // P:253
-    stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * divdp[r]));   // P:254
-    stream_store<SNT>(phi_out + off, phi);                                        // P:294,303,309
-    stream_store<SNT>(omega_p + off, cur.om + k.eta_ave_w * om);                  // P:173
-    dbl2 vn;
-    vn.x = cur.vn0.x + k.eta_ave_w * (u[r] * dp[r]);              // P:117
-    vn.y = cur.vn0.y + k.eta_ave_w * (v[r] * dp[r]);              // P:118
-    stream_store<SNT>(vn0 + off, vn);
-    stream_store<SNT>(eta + off, cur.eta + eta_zero);              // P:172
-    cur = nxt;
+      dbl2 vo;
+      vo.x = spheremp * (cur.vnm1.x + k.dt2 * vtens1);              // P:251
+      vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);              // P:252
+      stream_store<SNT>(v_np1 + off, vo);
+      stream_store<SNT>(T_np1 + off, spheremp * (cur.Tnm1 + k.dt2 * ttens));        // P:253
+      stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * divdp[r]));   // P:254
+      stream_store<SNT>(phi_out + off, phi);                                        // P:294,303,309
+      stream_store<SNT>(omega_p + off, cur.om + k.eta_ave_w * om);                  // P:173
+      dbl2 vn;
+      vn.x = cur.vn0.x + k.eta_ave_w * (u[r] * dp[r]);              // P:117
+      vn.y = cur.vn0.y + k.eta_ave_w * (v[r] * dp[r]);              // P:118
+      stream_store<SNT>(vn0 + off, vn);
+      stream_store<SNT>(eta + off, cur.eta + eta_zero);             // P:172
+      cur = nxt;
+    }
+    if (tid < PP) eta_last[ulane] = l_eta_last + eta_zero;          // P:181
+
+    if (!PERSIST || nxt_ie < 0) break;
+    in = nxt_in;
+    ie_s = nxt_ie;
+    par ^= 1;
   }
-  if (tid < PP) eta_last[ulane] = l_eta_last + eta_zero;          // P:181
 }
 
 // explicit instantiations + launchers --------------------------------------------------
-template <int NLEV, int TPW, int MINW, bool NT, int PF = 0>
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int NLEV, int TPW, int MINW, bool NT, int PF = 0, int PERSIST_WG_PER_CU = 0>
 static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = NLEV / 4 / TPW * 64;
+  constexpr bool PERSIST = PERSIST_WG_PER_CU > 0;
+  int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
+  if (PERSIST) {
+    grid = cu_count() * PERSIST_WG_PER_CU;
+    if (grid > num_elems) grid = num_elems;
+  }
   if (k.qn0 >= 0)
-    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true, NT, PF>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true, NT, PF, PERSIST>), dim3(grid), dim3(THREADS), 0, stream, k);
   else  // dry branch (P:128-139): the Qdp block is never touched
-    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false, NT, PF>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false, NT, PF, PERSIST>), dim3(grid), dim3(THREADS), 0, stream, k);
   return hipGetLastError();
 }
 
@@ -369,21 +357,24 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
-    {"caar_np4_kernel<72, 2, 1, true, true, 1>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1>},
-    {"caar_np4_kernel<72, 2, 1, true, true, 0>", "9 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<72, 2, 1, true, 0>},
-    {"caar_np4_kernel<72, 2, 1, true, false, 1>", "9 waves x 2 tiles, default cache policy", launch_np4<72, 2, 1, false, 1>},
-    {"caar_np4_kernel<72, 3, 2, true, true, 1>", "6 waves x 3 tiles, nt, update loads before the last barrier", launch_np4<72, 3, 2, true, 1>},
-    {"caar_np4_kernel<72, 3, 3, true, true, 0>", "6 waves x 3 tiles, <=168 VGPR: 2 workgroups/CU, nt", launch_np4<72, 3, 3, true, 0>},
-    {"caar_np4_kernel<72, 6, 1, true, true, 0>", "3 waves x 6 tiles, nt", launch_np4<72, 6, 1, true, 0>},
+    {"caar_np4_kernel<72, 2, 1, true, true, 1, false>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1>},
+    {"caar_np4_kernel<72, 2, 1, true, true, 1, true>", "persistent (1 workgroup/CU), 9 waves x 2 tiles, nt", launch_np4<72, 2, 1, true, 1, 1>},
+    {"caar_np4_kernel<72, 2, 1, true, true, 0, true>", "persistent (1 workgroup/CU), 9 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<72, 2, 1, true, 0, 1>},
+    {"caar_np4_kernel<72, 3, 2, true, true, 1, true>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt", launch_np4<72, 3, 2, true, 1, 1>},
+    {"caar_np4_kernel<72, 3, 2, true, true, 0, true>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt, update loads one tile ahead", launch_np4<72, 3, 2, true, 0, 1>},
+    {"caar_np4_kernel<72, 2, 1, true, true, 0, false>", "9 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<72, 2, 1, true, 0>},
+    {"caar_np4_kernel<72, 2, 1, true, false, 1, false>", "9 waves x 2 tiles, default cache policy", launch_np4<72, 2, 1, false, 1>},
+    {"caar_np4_kernel<72, 3, 2, true, true, 1, false>", "6 waves x 3 tiles, nt, update loads before the last barrier", launch_np4<72, 3, 2, true, 1>},
+    {"caar_np4_kernel<72, 6, 1, true, true, 0, false>", "3 waves x 6 tiles, nt", launch_np4<72, 6, 1, true, 0>},
 };
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
-    {"caar_np4_kernel<128, 4, 2, true, true, 1>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1>},
-    {"caar_np4_kernel<128, 4, 2, true, true, 0>", "8 waves x 4 tiles, nt, update loads one tile ahead", launch_np4<128, 4, 2, true, 0>},
-    {"caar_np4_kernel<128, 4, 2, true, false, 1>", "8 waves x 4 tiles, default cache policy", launch_np4<128, 4, 2, false, 1>},
-    {"caar_np4_kernel<128, 2, 2, true, true, 1>", "16 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<128, 2, 2, true, 1>},
-    {"caar_np4_kernel<128, 8, 1, true, true, 0>", "4 waves x 8 tiles, nt", launch_np4<128, 8, 1, true, 0>},
+    {"caar_np4_kernel<128, 4, 2, true, true, 1, false>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1>},
+    {"caar_np4_kernel<128, 4, 2, true, true, 1, true>", "persistent (1 workgroup/CU), 8 waves x 4 tiles, nt", launch_np4<128, 4, 2, true, 1, 1>},
+    {"caar_np4_kernel<128, 4, 2, true, true, 0, false>", "8 waves x 4 tiles, nt, update loads one tile ahead", launch_np4<128, 4, 2, true, 0>},
+    {"caar_np4_kernel<128, 4, 2, true, false, 1, false>", "8 waves x 4 tiles, default cache policy", launch_np4<128, 4, 2, false, 1>},
+    {"caar_np4_kernel<128, 8, 1, true, true, 0, false>", "4 waves x 8 tiles, nt", launch_np4<128, 8, 1, true, 0>},
 };
 int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 

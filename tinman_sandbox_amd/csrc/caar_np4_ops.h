@@ -1,0 +1,97 @@
+// caar_np4_ops.h — the three sphere operators for NP=4 on one 16-lane DPP row.
+//
+// gradient_sphere / divergence_sphere / vorticity_sphere of the reference
+// (compute_and_apply_rhs_test/cxx/pointers_only/sphere_operators.cpp:9-129, cited as S:)
+// for lane = a*4 + b of a 16-lane row holding one level of one element.  Used by the
+// fused kernel (caar_np4.hip) and by the stand-alone operator entry point
+// (caar_operators.hip, caar_sphere_operator).
+#ifndef CAAR_NP4_OPS_H
+#define CAAR_NP4_OPS_H
+
+#include <hip/hip_runtime.h>
+
+namespace caar {
+
+// ---------------------------------------------------------------- DPP helpers
+// dpp_ctrl encodings (LLVM AMDGPU): quad_perm = p0|p1<<2|p2<<4|p3<<6,
+// row_ror:n = 0x120+n.  All lanes have a valid source for these controls.
+template <int CTRL>
+__device__ __forceinline__ double dpp(double x) {
+  return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ int dppi(int x) {
+  return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, true);
+}
+
+// Per-lane slices of Dvv for lane (a, b) of a 16-lane row:
+//   ca[r] = Dvv[k_r][a] where k_r is the `a` index of the lane that row_ror:(4r)
+//           delivers to this lane (found by rotating the lane id itself, so the
+//           code does not depend on the rotate direction),
+//   cb[k] = Dvv[k][b].
+struct RowCoef {
+  double ca[4];
+  double cb[4];
+};
+
+// sum_k Dvv[k][a] f[k][b]   (derivative along the first GLL index; S:30,81,121)
+__device__ __forceinline__ double d_da(const RowCoef& c, double f) {
+  double s = c.ca[0] * f;
+  s += c.ca[1] * dpp<0x124>(f);
+  s += c.ca[2] * dpp<0x128>(f);
+  s += c.ca[3] * dpp<0x12C>(f);
+  return s;
+}
+// sum_k Dvv[k][b] f[a][k]   (derivative along the second GLL index; S:31,82,122)
+__device__ __forceinline__ double d_db(const RowCoef& c, double f) {
+  double s = c.cb[0] * dpp<0x00>(f);
+  s += c.cb[1] * dpp<0x55>(f);
+  s += c.cb[2] * dpp<0xAA>(f);
+  s += c.cb[3] * dpp<0xFF>(f);
+  return s;
+}
+
+// Metric 2x2 of this lane's point, row-major m[r][c] -> {m00, m01, m10, m11}.
+struct M22 {
+  double m00, m01, m10, m11;
+};
+
+// gradient_sphere, S:9-48
+__device__ __forceinline__ void gradient_sphere(const RowCoef& c, const M22& Dinv, double rrearth,
+                                                double s, double& g0, double& g1) {
+  const double v1 = d_da(c, s) * rrearth;
+  const double v2 = d_db(c, s) * rrearth;
+  g0 = Dinv.m00 * v1 + Dinv.m10 * v2;
+  g1 = Dinv.m01 * v1 + Dinv.m11 * v2;
+}
+// divergence_sphere, S:50-89
+__device__ __forceinline__ double divergence_sphere(const RowCoef& c, const M22& Dinv, double metdet,
+                                                    double rmetdet, double rrearth, double u, double v) {
+  const double gv0 = metdet * (Dinv.m00 * u + Dinv.m01 * v);
+  const double gv1 = metdet * (Dinv.m10 * u + Dinv.m11 * v);
+  return (d_da(c, gv0) + d_db(c, gv1)) * rmetdet * rrearth;
+}
+// vorticity_sphere, S:91-129
+__device__ __forceinline__ double vorticity_sphere(const RowCoef& c, const M22& D, double rmetdet,
+                                                   double rrearth, double u, double v) {
+  const double vc0 = D.m00 * u + D.m10 * v;
+  const double vc1 = D.m01 * u + D.m11 * v;
+  return (d_da(c, vc1) - d_db(c, vc0)) * rmetdet * rrearth;
+}
+
+// Per-lane Dvv slices for lane `lane` from a 16-entry Dvv table (LDS or global).
+__device__ __forceinline__ RowCoef make_row_coef(const double* dvv, int lane) {
+  RowCoef c;
+  const int pt = lane & 15, a = pt >> 2, b = pt & 3;
+  const int s1 = dppi<0x124>(lane), s2 = dppi<0x128>(lane), s3 = dppi<0x12C>(lane);
+  c.ca[0] = dvv[a * 4 + a];
+  c.ca[1] = dvv[((s1 >> 2) & 3) * 4 + a];
+  c.ca[2] = dvv[((s2 >> 2) & 3) * 4 + a];
+  c.ca[3] = dvv[((s3 >> 2) & 3) * 4 + a];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) c.cb[kk] = dvv[kk * 4 + b];
+  return c;
+}
+
+}  // namespace caar
+#endif

@@ -23,92 +23,10 @@
 #include <hip/hip_runtime.h>
 
 #include "caar_kernel_args.h"
+#include "caar_np8_ops.h"
 
 namespace caar {
 
-namespace np8 {
-
-constexpr int NP = 8, PP = 64;
-enum { G_FCOR = 0, G_SPHEREMP = 64, G_METDET = 128, G_RMETDET = 192, G_PHIS = 256, G_D = 320, G_DINV = 576, G_SIZE = 832 };
-
-// wave-private LDS is written and read by different lanes of the same wave: LDS
-// instructions of one wave execute in order, the fence only pins the compiler.
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-struct Ctx {
-  double ca[NP];  // ca[k] = Dvv[k][a]
-  double cb[NP];  // cb[k] = Dvv[k][b]
-  double* tile;   // LDS, this wave's 64-double tile
-  int a, b;
-};
-
-// sum_k Dvv[k][a] f[k][b] and sum_k Dvv[k][b] f[a][k] of the field currently in c.tile
-__device__ __forceinline__ double d_da_tile(const Ctx& c) {
-  double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < NP; ++k) s += c.ca[k] * c.tile[k * NP + c.b];
-  return s;
-}
-__device__ __forceinline__ double d_db_tile(const Ctx& c) {
-  double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < NP; ++k) s += c.cb[k] * c.tile[c.a * NP + k];
-  return s;
-}
-__device__ __forceinline__ void put_tile(const Ctx& c, int lane, double f) {
-  wave_lds_fence();  // earlier reads of the tile are done
-  c.tile[lane] = f;
-  wave_lds_fence();
-}
-
-struct M22 {
-  double m00, m01, m10, m11;
-};
-__device__ __forceinline__ M22 load_m22(const double* g, int pt) {
-  M22 m;
-  m.m00 = g[pt * 4 + 0];
-  m.m01 = g[pt * 4 + 1];
-  m.m10 = g[pt * 4 + 2];
-  m.m11 = g[pt * 4 + 3];
-  return m;
-}
-
-// gradient_sphere, S:9-48
-__device__ __forceinline__ void gradient_sphere(const Ctx& c, int lane, const M22& Dinv, double rrearth,
-                                                double s, double& g0, double& g1) {
-  put_tile(c, lane, s);
-  const double v1 = d_da_tile(c) * rrearth;
-  const double v2 = d_db_tile(c) * rrearth;
-  g0 = Dinv.m00 * v1 + Dinv.m10 * v2;
-  g1 = Dinv.m01 * v1 + Dinv.m11 * v2;
-}
-// divergence_sphere, S:50-89
-__device__ __forceinline__ double divergence_sphere(const Ctx& c, int lane, const M22& Dinv, double metdet,
-                                                    double rmetdet, double rrearth, double u, double v) {
-  const double gv0 = metdet * (Dinv.m00 * u + Dinv.m01 * v);
-  const double gv1 = metdet * (Dinv.m10 * u + Dinv.m11 * v);
-  put_tile(c, lane, gv0);
-  const double dudx = d_da_tile(c);
-  put_tile(c, lane, gv1);
-  const double dvdy = d_db_tile(c);
-  return (dudx + dvdy) * rmetdet * rrearth;
-}
-// vorticity_sphere, S:91-129
-__device__ __forceinline__ double vorticity_sphere(const Ctx& c, int lane, const M22& D, double rmetdet,
-                                                   double rrearth, double u, double v) {
-  const double vc0 = D.m00 * u + D.m10 * v;
-  const double vc1 = D.m01 * u + D.m11 * v;
-  put_tile(c, lane, vc1);
-  const double dvdx = d_da_tile(c);
-  put_tile(c, lane, vc0);
-  const double dudy = d_db_tile(c);
-  return (dvdx - dudy) * rmetdet * rrearth;
-}
-
-}  // namespace np8
 
 template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT>
 __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const KernelArgs k) {
@@ -218,27 +136,6 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   }
   __syncthreads();
 
-  // ---- phase 2: hydrostatic increments, their suffix sums inside the wave ---------------
-  double base_dp = 0.0, base_div = 0.0;  // sums over the levels above this wave's first level
-  for (int w2 = 0; w2 < w; ++w2) {
-    base_dp += s_tot_dp[w2 * PP + pt];
-    base_div += s_tot_div[w2 * PP + pt];
-  }
-  double wave_ht;  // sum of the hydrostatic increments over this wave's levels
-  {
-    double run = base_dp, acc = 0.0;
-#pragma unroll
-    for (int r = 0; r < TPW; ++r) {
-      const double dpr = park_rd[r * PP];
-      const double p = (k.p_top + run) + 0.5 * dpr;         // P:84,94-96 in closed form
-      run += dpr;
-      acc += (k.Rgas * Tv[r]) * (dpr * recip(p));           // Rgas*T_v*hkl, hkl = dp/p (P:300-302)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    wave_ht = acc;
-    s_tot_ht[w * PP + pt] = acc;
-  }
-
   const dbl2* __restrict__ v_nm1 = reinterpret_cast<const dbl2*>(k.v + (ie * tl + k.nm1) * BLK * 2) + wbase;
   const double* __restrict__ T_nm1 = k.T + (ie * tl + k.nm1) * BLK + wbase;
   const double* __restrict__ dp_nm1 = k.dp3d + (ie * tl + k.nm1) * BLK + wbase;
@@ -268,7 +165,29 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     x.eta = stream_load<SNT>(eta + off);
     return x;
   };
-  LevelIn cur = load_level(0);  // in flight across the barrier
+  LevelIn cur = load_level(0);  // requested before phase 2: in flight across it and the barrier
+
+  // ---- phase 2: hydrostatic increments, their suffix sums inside the wave ---------------
+  double base_dp = 0.0, base_div = 0.0;  // sums over the levels above this wave's first level
+  for (int w2 = 0; w2 < w; ++w2) {
+    base_dp += s_tot_dp[w2 * PP + pt];
+    base_div += s_tot_div[w2 * PP + pt];
+  }
+  double wave_ht;  // sum of the hydrostatic increments over this wave's levels
+  {
+    double run = base_dp, acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) {
+      const double dpr = park_rd[r * PP];
+      const double p = (k.p_top + run) + 0.5 * dpr;         // P:84,94-96 in closed form
+      run += dpr;
+      acc += (k.Rgas * Tv[r]) * (dpr * recip(p));           // Rgas*T_v*hkl, hkl = dp/p (P:300-302)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_ht = acc;
+    s_tot_ht[w * PP + pt] = acc;
+  }
+
   double l_eta_last = 0.0;
   if (tid < PP) l_eta_last = eta_last[ulane];
   __syncthreads();
