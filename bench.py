@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--nlev", type=int, default=72)
     ap.add_argument("--elems-per-gpu", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short extra measurements of BASELINE.json configs[3] and [4]")
     ap.add_argument("--cpu-seconds", type=float, default=1.5,
                     help="target wall seconds per host thread for the CPU baseline sample")
     return ap.parse_args()
@@ -119,6 +121,35 @@ def cpu_baseline(np_, nlev, seconds):
             "oracle/_ref (reference cxx/pointers_only, g++ -O3)" if use_ref else "oracle/caar_oracle.c (gcc -O2)",
             np_, nlev, wall),
     }
+
+
+def measure_config(tsa, torch, dev, np_, nlev, elems, steps, warmup):
+    """Kernel-only measurement of one more configuration (HIP events on the launch stream)."""
+    data = tsa.TestData().init_data(elems, np_, nlev, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    for _ in range(warmup):
+        tsa.compute_and_apply_rhs(data, stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(steps):
+        tsa.compute_and_apply_rhs(data, stream)
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / steps
+    balg = tsa.algorithmic_bytes(np_, nlev)
+    gbs = balg * elems / (ms * 1e-3) / 1e9
+    del data
+    torch.cuda.empty_cache()
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(
+            "np%d_nlev%d_e%d" % (np_, nlev, elems), {}).get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return {"workload": "NP=%d NLEV=%d num_elems=%d" % (np_, nlev, elems), "kernel_ms": ms, "traffic": traffic,
+            "element_updates_per_s": elems / (ms * 1e-3), "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_element": balg,
+            "kernel": tsa.library().lib.caar_kernel_name(np_, nlev).decode()}
 
 
 def main():
@@ -229,6 +260,13 @@ def main():
                 "kernel_ms": kernel_ms_max,
             },
         }
+        if world == 1 and not args.no_other_configs and (args.np_, args.nlev) == (4, 72):
+            # BASELINE.json configs[3] (NP=4 NLEV=128, one GPU's share of 100 000 elements) and
+            # configs[4] (NP=8, 20 000 elements), kernel-only, same run; the headline stays configs[1]
+            del data
+            torch.cuda.empty_cache()
+            out["other_configs"] = [measure_config(tsa, torch, dev, 4, 128, 12500, 20, 3),
+                                    measure_config(tsa, torch, dev, 8, 72, 20000, 10, 2)]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.np_, args.nlev, args.cpu_seconds)
         print(json.dumps(out))

@@ -28,7 +28,7 @@
 namespace caar {
 
 
-template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT>
+template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T>
 __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const KernelArgs k) {
   using namespace np8;
   constexpr int WAVES = NLEV / TPW;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     N0In x;
     x.dp = stream_load<SNT>(dp_n0 + off);
     x.uv = stream_load<SNT>(v_n0 + off);
-    x.T = stream_load<SNT>(T_n0 + off);
+    x.T = stream_load<SNT && !RELOAD_T>(T_n0 + off);  // RELOAD_T: default policy, re-read from L2 in phase 3
     x.q = MOIST ? stream_load<SNT>(Qdp + off) : 0.0;
     return x;
   };
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   N0In ring[PD];
 #pragma unroll
   for (int r = 0; r < PD; ++r) ring[r] = load_n0(r);
-  double T[TPW], Tv[TPW];
+  double T[RELOAD_T ? 1 : TPW], Tv[TPW];
   double* const park_dp = s_park + lev0 * PP + lane;  // + r*PP; u, v follow at BLK strides
   // volatile reads: the compiler must not forward the parked values through registers
   const volatile double* const park_rd = park_dp;
@@ -103,10 +103,13 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   c.tile = s_tile + w * 64;
   c.a = lane >> 3;
   c.b = lane & 7;
+  c.dvvT = s_dvvT;
+  if (!COEF_LDS) {
 #pragma unroll
-  for (int kk = 0; kk < NP; ++kk) {
-    c.ca[kk] = s_dvvT[c.a * NP + kk];
-    c.cb[kk] = s_dvvT[c.b * NP + kk];
+    for (int kk = 0; kk < NP; ++kk) {
+      c.ca[kk] = s_dvvT[c.a * NP + kk];
+      c.cb[kk] = s_dvvT[c.b * NP + kk];
+    }
   }
   const double rrearth = k.rrearth;
   const double rmetdet = s_geo[G_RMETDET + pt];
@@ -121,8 +124,8 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     for (int r = 0; r < TPW; ++r) {
       const N0In x = ring[r % PD];
       if (r + PD < TPW) ring[r % PD] = load_n0(r + PD);
-      divdp[r] = divergence_sphere(c, lane, Dinv, metdet, rmetdet, rrearth, x.uv.x * x.dp, x.uv.y * x.dp);  // P:114-121
-      T[r] = x.T;
+      divdp[r] = divergence_sphere<COEF_LDS>(c, lane, Dinv, metdet, rmetdet, rrearth, x.uv.x * x.dp, x.uv.y * x.dp);  // P:114-121
+      if (!RELOAD_T) T[r] = x.T;
       Tv[r] = MOIST ? x.T * (1.0 + k.rv_over_rd_m1 * (x.q * recip(x.dp))) : x.T;  // P:135,150-151
       run_dp += x.dp;
       run_div += divdp[r];
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
 
   struct LevelIn {
     dbl2 vnm1, vn0;
-    double Tnm1, dpnm1, om, pec, eta;
+    double Tnm1, dpnm1, om, pec, eta, Tn0;
   };
   auto load_level = [&](int r) {
     const unsigned off = r * PP + ulane;
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     x.om = stream_load<SNT>(omega_p + off);
     x.pec = stream_load<SNT>(pecnd + off);
     x.eta = stream_load<SNT>(eta + off);
+    x.Tn0 = RELOAD_T ? stream_load<SNT>(T_n0 + off) : 0.0;
     return x;
   };
   LevelIn cur = load_level(0);  // requested before phase 2: in flight across it and the barrier
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     if (r + 1 < TPW) nxt = load_level(r + 1);
 
     const double dpr = park_rd[r * PP], ur = park_rd[BLK + r * PP], vr = park_rd[2 * BLK + r * PP];
-    const double Tr = T[r];
+    const double Tr = RELOAD_T ? cur.Tn0 : T[RELOAD_T ? 0 : r];
 
     const double p = (k.p_top + run_dp) + 0.5 * dpr;
     run_dp += dpr;
@@ -221,18 +225,18 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     const double phi = (phis + (below + (wave_ht - run_ht))) + 0.5 * ht;  // P:303,309
 
     double gp0, gp1;
-    gradient_sphere(c, lane, Dinv, rrearth, p, gp0, gp1);              // P:103
+    gradient_sphere<COEF_LDS>(c, lane, Dinv, rrearth, p, gp0, gp1);              // P:103
     const double vgrad_p = ur * gp0 + vr * gp1;                    // P:111
     const double ckk = 0.5 * rp, ckl = rp;                             // P:333-334
     const double om = vgrad_p * rp - ckl * suml - ckk * divdp[r];      // P:325,336,348
     suml += divdp[r];                                                  // P:339
-    const double vort = vorticity_sphere(c, lane, Dm, rmetdet, rrearth, ur, vr);  // P:122
+    const double vort = vorticity_sphere<COEF_LDS>(c, lane, Dm, rmetdet, rrearth, ur, vr);  // P:122
 
     const double Ephi = 0.5 * (ur * ur + vr * vr) + phi + cur.pec;  // P:196
     double gT0, gT1, gE0, gE1;
-    gradient_sphere(c, lane, Dinv, rrearth, Tr, gT0, gT1);           // P:200
+    gradient_sphere<COEF_LDS>(c, lane, Dinv, rrearth, Tr, gT0, gT1);           // P:200
     const double vgrad_T = ur * gT0 + vr * gT1;                    // P:209
-    gradient_sphere(c, lane, Dinv, rrearth, Ephi, gE0, gE1);           // P:213
+    gradient_sphere<COEF_LDS>(c, lane, Dinv, rrearth, Ephi, gE0, gE1);           // P:213
     const double gpterm = Tv[r] * rp;                                  // P:219
     const double glnps1 = k.Rgas * gpterm * gp0;                       // P:221
     const double glnps2 = k.Rgas * gpterm * gp1;                       // P:222
@@ -259,22 +263,24 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   if (tid < PP) eta_last[ulane] = l_eta_last + eta_zero;               // P:181
 }
 
-template <int NLEV, int TPW, int MINW, bool NT>
+template <int NLEV, int TPW, int MINW, bool NT, bool COEF_LDS = false, bool RELOAD_T = false>
 static hipError_t launch_np8(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = NLEV / TPW * 64;
+  const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
   if (k.qn0 >= 0)
-    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT, COEF_LDS, RELOAD_T>), dim3(grid), dim3(THREADS), 0, stream, k);
   else  // dry branch (P:128-139)
-    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false, NT>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false, NT, COEF_LDS, RELOAD_T>), dim3(grid), dim3(THREADS), 0, stream, k);
   return hipGetLastError();
 }
 
 // (non-const on purpose, see caar_np4.hip)
 KernelVariant kNp8Nlev72[] = {
-    {"caar_np8_kernel<72, 9, 1, true, true>", "8 waves x 9 levels, nt", launch_np8<72, 9, 1, true>},
-    {"caar_np8_kernel<72, 9, 1, true, false>", "8 waves x 9 levels", launch_np8<72, 9, 1, false>},
-    {"caar_np8_kernel<72, 18, 1, true, true>", "4 waves x 18 levels (one wave per SIMD, 512 registers), nt", launch_np8<72, 18, 1, true>},
-    {"caar_np8_kernel<72, 12, 1, true, true>", "6 waves x 12 levels, nt", launch_np8<72, 12, 1, true>},
+    {"caar_np8_kernel<72, 9, 1, true, true, true, false>", "8 waves x 9 levels, nt, Dvv slices re-read from LDS", launch_np8<72, 9, 1, true, true, false>},
+    {"caar_np8_kernel<72, 9, 1, true, true, true, true>", "8 waves x 9 levels, nt, Dvv slices from LDS, T re-read in the last phase", launch_np8<72, 9, 1, true, true, true>},
+    {"caar_np8_kernel<72, 9, 1, true, true, false, false>", "8 waves x 9 levels, nt, Dvv slices in registers", launch_np8<72, 9, 1, true, false, false>},
+    {"caar_np8_kernel<72, 9, 1, true, false, true, false>", "8 waves x 9 levels, default cache policy", launch_np8<72, 9, 1, false, true, false>},
+    {"caar_np8_kernel<72, 18, 1, true, true, false, false>", "4 waves x 18 levels (one wave per SIMD, 512 registers), nt", launch_np8<72, 18, 1, true, false, false>},
 };
 int kNp8Nlev72Count = sizeof(kNp8Nlev72) / sizeof(kNp8Nlev72[0]);
 

@@ -20,24 +20,30 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Dvv slices of lane (a, b): ca[k] = Dvv[k][a], cb[k] = Dvv[k][b].  Either held in
+// registers (32 VGPRs) or re-read from the transposed LDS copy dvvT[j*8+k] = Dvv[k][j] at
+// every use (4 x ds_read_b128 per slice) when the kernel needs the registers.
 struct Ctx {
-  double ca[NP];  // ca[k] = Dvv[k][a]
-  double cb[NP];  // cb[k] = Dvv[k][b]
-  double* tile;   // LDS, this wave's 64-double tile
+  double ca[NP];
+  double cb[NP];
+  const double* dvvT;  // LDS copy, or nullptr when ca/cb are valid
+  double* tile;        // LDS, this wave's 64-double tile
   int a, b;
 };
 
 // sum_k Dvv[k][a] f[k][b] and sum_k Dvv[k][b] f[a][k] of the field currently in c.tile
+template <bool COEF_LDS>
 __device__ __forceinline__ double d_da_tile(const Ctx& c) {
   double s = 0.0;
 #pragma unroll
-  for (int k = 0; k < NP; ++k) s += c.ca[k] * c.tile[k * NP + c.b];
+  for (int k = 0; k < NP; ++k) s += (COEF_LDS ? c.dvvT[c.a * NP + k] : c.ca[k]) * c.tile[k * NP + c.b];
   return s;
 }
+template <bool COEF_LDS>
 __device__ __forceinline__ double d_db_tile(const Ctx& c) {
   double s = 0.0;
 #pragma unroll
-  for (int k = 0; k < NP; ++k) s += c.cb[k] * c.tile[c.a * NP + k];
+  for (int k = 0; k < NP; ++k) s += (COEF_LDS ? c.dvvT[c.b * NP + k] : c.cb[k]) * c.tile[c.a * NP + k];
   return s;
 }
 __device__ __forceinline__ void put_tile(const Ctx& c, int lane, double f) {
@@ -59,34 +65,37 @@ __device__ __forceinline__ M22 load_m22(const double* g, int pt) {
 }
 
 // gradient_sphere, S:9-48
+template <bool COEF_LDS = false>
 __device__ __forceinline__ void gradient_sphere(const Ctx& c, int lane, const M22& Dinv, double rrearth,
                                                 double s, double& g0, double& g1) {
   put_tile(c, lane, s);
-  const double v1 = d_da_tile(c) * rrearth;
-  const double v2 = d_db_tile(c) * rrearth;
+  const double v1 = d_da_tile<COEF_LDS>(c) * rrearth;
+  const double v2 = d_db_tile<COEF_LDS>(c) * rrearth;
   g0 = Dinv.m00 * v1 + Dinv.m10 * v2;
   g1 = Dinv.m01 * v1 + Dinv.m11 * v2;
 }
 // divergence_sphere, S:50-89
+template <bool COEF_LDS = false>
 __device__ __forceinline__ double divergence_sphere(const Ctx& c, int lane, const M22& Dinv, double metdet,
                                                     double rmetdet, double rrearth, double u, double v) {
   const double gv0 = metdet * (Dinv.m00 * u + Dinv.m01 * v);
   const double gv1 = metdet * (Dinv.m10 * u + Dinv.m11 * v);
   put_tile(c, lane, gv0);
-  const double dudx = d_da_tile(c);
+  const double dudx = d_da_tile<COEF_LDS>(c);
   put_tile(c, lane, gv1);
-  const double dvdy = d_db_tile(c);
+  const double dvdy = d_db_tile<COEF_LDS>(c);
   return (dudx + dvdy) * rmetdet * rrearth;
 }
 // vorticity_sphere, S:91-129
+template <bool COEF_LDS = false>
 __device__ __forceinline__ double vorticity_sphere(const Ctx& c, int lane, const M22& D, double rmetdet,
                                                    double rrearth, double u, double v) {
   const double vc0 = D.m00 * u + D.m10 * v;
   const double vc1 = D.m01 * u + D.m11 * v;
   put_tile(c, lane, vc1);
-  const double dvdx = d_da_tile(c);
+  const double dvdx = d_da_tile<COEF_LDS>(c);
   put_tile(c, lane, vc0);
-  const double dudy = d_db_tile(c);
+  const double dudy = d_db_tile<COEF_LDS>(c);
   return (dvdx - dudy) * rmetdet * rrearth;
 }
 

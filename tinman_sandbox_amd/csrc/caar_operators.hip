@@ -56,6 +56,7 @@ __global__ void sphere_operator_np8(int which, const double* __restrict__ in, do
   const int lev = blockIdx.x * (blockDim.x >> 6) + w;
   if (lev >= nlevels) return;  // wave-uniform
   np8::Ctx c;
+  c.dvvT = nullptr;
   c.tile = s_tile + w * 64;
   c.a = lane >> 3;
   c.b = lane & 7;
