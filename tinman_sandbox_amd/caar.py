@@ -413,8 +413,10 @@ def compute_and_apply_rhs(data, stream=None):
     if stream is None:
         stream = torch.cuda.current_stream(data.arrays.device)
     dims, ptrs, prm = data.arrays.dims(), data.arrays.pointers(), data.params()
-    rc = L.lib.caar_launch(C.byref(dims), C.byref(ptrs), C.c_void_p(data.dvv_device().data_ptr()),
-                           C.byref(prm), C.c_void_p(stream.cuda_stream))
+    dvv = data.dvv_device()
+    with torch.cuda.device(data.arrays.device):  # the launch goes to the calling thread's current HIP device
+        rc = L.lib.caar_launch(C.byref(dims), C.byref(ptrs), C.c_void_p(dvv.data_ptr()),
+                               C.byref(prm), C.c_void_p(stream.cuda_stream))
     L.check(rc, "caar_launch")
 
 
