@@ -111,3 +111,31 @@ def test_single_element_and_large_offsets(oracle):
         got = data.arrays[n].cpu().numpy()
         assert cases.scaled_err(got[E - 1], ref[n][E - 1]) <= 1e-12, n
         assert torch.equal(data.arrays[n][: E - 1], before[n][: E - 1]), n
+
+
+def test_eta_noop_update_is_bit_faithful(oracle):
+    """P:172,181: eta_dot_dpdn += eta_ave_w * 0.  Arithmetically a no-op, but -0.0 becomes +0.0
+    and the reference does perform the read-modify-write; the default kernel does too, and
+    the variant that stores only changed values must end with the same bits."""
+    lib = tsa.library().lib
+    arrs, Dvv, sc = cases.make_case("np4_nlev72_hashed")
+    eta = arrs["elem_derived_eta_dot_dpdn"]
+    eta[1, ::7] = -0.0
+    eta[2, 3] = 0.0
+    want = cases.copy_arrays(arrs)
+    oracle.compute_and_apply_rhs(want, Dvv, sc)
+    w = want["elem_derived_eta_dot_dpdn"]
+    assert not np.signbit(w[1, ::7]).any() and np.signbit(arrs["elem_derived_eta_dot_dpdn"][1, ::7]).all()
+    names = [lib.caar_variant_info(4, 72, v).decode() for v in range(lib.caar_num_variants(4, 72))]
+    cond = [i for i, n in enumerate(names) if "bits change" in n]
+    assert cond, names
+    try:
+        for v in [0] + cond:
+            lib.caar_select_variant(4, 72, v)
+            data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+            tsa.compute_and_apply_rhs(data)
+            torch.cuda.synchronize()
+            got = data.arrays["elem_derived_eta_dot_dpdn"].cpu().numpy()
+            assert np.array_equal(got.view(np.int64), w.view(np.int64)), v  # bit for bit, incl. the sign of zero
+    finally:
+        lib.caar_select_variant(4, 72, 0)
