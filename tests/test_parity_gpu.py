@@ -258,3 +258,31 @@ def test_sphere_operators_match_oracle(oracle, np_, nlev):
             assert cases.scaled_err(g[k], wg) <= 1e-14, (ie, k)
             assert cases.scaled_err(d[k], wd) <= 1e-14, (ie, k)
             assert cases.scaled_err(w[k], ww) <= 1e-14, (ie, k)
+
+
+def test_randomised_controls_match_oracle(oracle):
+    """Seeded sweep over what Homme::Control / Constants can hold: every permutation of the
+    three time levels, both Qdp slots and the dry branch, element sub-ranges, and
+    magnitudes of dt2 / eta_ave_w / rrearth / ps0."""
+    import itertools
+    perms = list(itertools.permutations(range(3)))
+    arrs = cases.hashed_arrays(4, 72, 5, seed=61)
+    Dvv = cases.dvv_for(4)
+    u = cases.uniform((len(perms), 6), 62)
+    for i, (n0, np1, nm1) in enumerate(perms):
+        sc = po.default_scalars(72)
+        nets = int(u[i, 0] * 3)
+        nete = nets + 1 + int(u[i, 1] * (5 - nets))
+        sc.update(n0=n0, np1=np1, nm1=nm1, qn0=[-1, 0, 1][i % 3], nets=nets, nete=min(nete, 5),
+                  dt2=10.0 ** (3 * u[i, 2] - 1), eta_ave_w=u[i, 3], rrearth=10.0 ** (-7 + 4 * u[i, 4]),
+                  ps0=1000.0 * u[i, 5])
+        want = cases.copy_arrays(arrs)
+        oracle.compute_and_apply_rhs(want, Dvv, sc)
+        _, got = run_gpu(arrs, Dvv, sc)
+        check_outputs(got, want, sc, "sweep%d" % i)
+        for n in po.ARRAY_NAMES:  # untouched elements and arrays stay bit-identical
+            if n not in cases.OUTPUT_NAMES:
+                assert np.array_equal(got[n], arrs[n]), (i, n)
+            else:
+                assert np.array_equal(got[n][:sc["nets"]], arrs[n][:sc["nets"]]), (i, n)
+                assert np.array_equal(got[n][sc["nete"]:], arrs[n][sc["nete"]:]), (i, n)
