@@ -125,6 +125,10 @@ int caar_sphere_operator(const CaarDims *dims, const CaarArrays *dev, const doub
                          int ie, int nlevels, const double *in_dev, double *out_dev, double rrearth,
                          void *stream);
 
+/* Numerics hook: out[i] = the kernels' reciprocal of in[i] (v_rcp_f64 + two Newton steps,
+ * used for the divisions by p and dp3d, P:150,219,291,323; <= 1 ulp for normal inputs). */
+int caar_reciprocal(const double *in_dev, double *out_dev, long long n, void *stream);
+
 /* print_results_2norm's per-element arithmetic (P:353-390) on device-resident arrays:
  * out_dev[3*(e-e0)+f] = pow(compute_norm(field_f of element e at time level tl), 2),
  * f = 0,1,2 for v, T, dp3d.  `out_dev` is a DEVICE buffer of 3*(e1-e0) doubles.

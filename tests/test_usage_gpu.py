@@ -139,3 +139,24 @@ def test_eta_noop_update_is_bit_faithful(oracle):
             assert np.array_equal(got.view(np.int64), w.view(np.int64)), v  # bit for bit, incl. the sign of zero
     finally:
         lib.caar_select_variant(4, 72, 0)
+
+
+def test_device_reciprocal_is_within_one_ulp():
+    """The kernels replace x/p by x*recip(p) (DESIGN.md "Numerics"): recip must be <= 1 ulp
+    from the correctly rounded 1/p over the whole range pressures can take."""
+    import ctypes as C
+    L = tsa.library()
+    n = 1 << 20
+    x = np.exp(cases.uniform((n,), 71, np.log(1e-6), np.log(1e9)))
+    x[:4] = [1.0, 2.0, 3.0, 1e5]
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty_like(xd)
+    st = torch.cuda.current_stream()
+    L.check(L.lib.caar_reciprocal(C.c_void_p(xd.data_ptr()), C.c_void_p(out.data_ptr()), n,
+                                  C.c_void_p(st.cuda_stream)), "caar_reciprocal")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    want = 1.0 / x
+    ulp = np.spacing(want)
+    assert np.max(np.abs(got - want) / ulp) <= 1.0
+    assert got[0] == 1.0 and got[1] == 0.5

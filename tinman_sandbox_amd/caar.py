@@ -58,7 +58,7 @@ class CaarLibrary:
     """ctypes view of libcaar_hip.so; every symbol of include/caar.h is bound here."""
 
     SYMBOLS = ("caar_supported", "caar_abi_version", "caar_strerror", "caar_array_len",
-               "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator",
+               "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator", "caar_reciprocal",
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
                "caar_variant_info", "caar_set_xcd_chunked", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_traffic_skeleton", "caar_create", "caar_destroy", "caar_upload", "caar_download",
                "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
@@ -86,6 +86,7 @@ class CaarLibrary:
                                               C.c_int, C.c_int, vp, vp]
         L.caar_sphere_operator.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays), vp, C.c_int, C.c_int,
                                            C.c_int, vp, vp, C.c_double, vp]
+        L.caar_reciprocal.argtypes = [vp, vp, C.c_longlong, vp]
         L.caar_kernel_name.argtypes = [C.c_int, C.c_int]
         L.caar_kernel_name.restype = C.c_char_p
         L.caar_num_variants.argtypes = [C.c_int, C.c_int]

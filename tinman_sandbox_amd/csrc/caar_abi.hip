@@ -29,6 +29,7 @@ hipError_t launch_stream_copy(double* dst, const double* src, size_t n_doubles, 
 hipError_t launch_sphere_operator(int np, int which, const double* in, double* out, const double* D,
                                   const double* Dinv, const double* metdet, const double* rmetdet,
                                   const double* dvv, int ie, int nlevels, double rrearth, hipStream_t s);
+hipError_t launch_reciprocal(const double* in, double* out, size_t n, hipStream_t s);
 hipError_t launch_layout(double* dst, const double* src, size_t n, int np, int nc, int nlev, int qd,
                          int qdp_outer, bool to_caar, hipStream_t s);
 hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t stream);
@@ -236,6 +237,11 @@ int caar_sphere_operator(const CaarDims* dims, const CaarArrays* dev, const doub
   return (int)caar::launch_sphere_operator(dims->np, which, in_dev, out_dev, dev->elem_D, dev->elem_Dinv,
                                            dev->elem_metdet, dev->elem_rmetdet, dvv_dev, ie, nlevels, rrearth,
                                            (hipStream_t)stream);
+}
+
+int caar_reciprocal(const double* in_dev, double* out_dev, long long n, void* stream) {
+  if (!in_dev || !out_dev || n < 0) return CAAR_EINVAL;
+  return (int)caar::launch_reciprocal(in_dev, out_dev, (size_t)n, (hipStream_t)stream);
 }
 
 // components per GLL point of array i (CaarArrays member order)

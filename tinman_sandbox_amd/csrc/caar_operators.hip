@@ -80,6 +80,18 @@ __global__ void sphere_operator_np8(int which, const double* __restrict__ in, do
   }
 }
 
+// recip() of caar_kernel_args.h on its own (numerics test hook: caar_reciprocal)
+__global__ void reciprocal_kernel(const double* __restrict__ in, double* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = recip(in[i]);
+}
+hipError_t launch_reciprocal(const double* in, double* out, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(reciprocal_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, in, out, n);
+  return hipGetLastError();
+}
+
 hipError_t launch_sphere_operator(int np, int which, const double* in, double* out, const double* D,
                                   const double* Dinv, const double* metdet, const double* rmetdet,
                                   const double* dvv, int ie, int nlevels, double rrearth, hipStream_t s) {
