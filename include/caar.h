@@ -94,6 +94,8 @@ typedef struct CaarParams {
 int caar_supported(int np, int nlev);
 /* CAAR_ABI_VERSION the library was built with. */
 int caar_abi_version(void);
+/* Number of HIP devices visible to the process (0 if none / no driver). */
+int caar_device_count(void);
 /* Static text for a return code. */
 const char *caar_strerror(int rc);
 /* Number of doubles in array `index` (0..15, CaarArrays member order) for `dims`,

@@ -50,6 +50,20 @@ def test_driver_prints_oracle_norms(np_, nlev, exe):
     assert np.allclose(blocks[3], after, rtol=1e-13, atol=0)
 
 
+def test_driver_shards_elements_over_devices():
+    """--tinman-num-devices: one DeviceSession + host thread per slab (on a one-GPU box the
+    slabs share the GPU); norms must equal the unsharded oracle's."""
+    path = os.path.join(ROOT, "tinman_sandbox_amd", "host", "caar_driver")
+    out = subprocess.run([path, "--tinman-num-elems=11", "--tinman-num-exec=2", "--tinman-num-devices=3"],
+                         check=True, capture_output=True, text=True, timeout=300).stdout
+    blocks = norms_in(out)
+    assert len(blocks) == 4, out
+    before, after = oracle_norms(4, 72, 11)
+    assert np.allclose(blocks[1], before, rtol=1e-14, atol=0)
+    assert np.allclose(blocks[2], after, rtol=1e-13, atol=0)
+    assert np.allclose(blocks[3], after, rtol=1e-13, atol=0)
+
+
 def test_reference_main_links_against_the_hip_path():
     exe = os.path.join(ROOT, "oracle", "_ref", "pointers_only_hip")
     if not os.path.exists(exe):

@@ -57,7 +57,7 @@ class CaarError(RuntimeError):
 class CaarLibrary:
     """ctypes view of libcaar_hip.so; every symbol of include/caar.h is bound here."""
 
-    SYMBOLS = ("caar_supported", "caar_abi_version", "caar_strerror", "caar_array_len",
+    SYMBOLS = ("caar_supported", "caar_abi_version", "caar_device_count", "caar_strerror", "caar_array_len",
                "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator", "caar_reciprocal",
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
                "caar_variant_info", "caar_set_xcd_chunked", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_traffic_skeleton", "caar_create", "caar_destroy", "caar_upload", "caar_download",

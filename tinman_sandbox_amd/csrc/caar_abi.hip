@@ -91,6 +91,11 @@ extern "C" {
 
 int caar_abi_version(void) { return CAAR_ABI_VERSION; }
 
+int caar_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int caar_supported(int np, int nlev) { return caar::find_config(np, nlev) != nullptr; }
 
 const char* caar_kernel_name(int np, int nlev) {

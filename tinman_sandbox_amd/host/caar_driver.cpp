@@ -10,10 +10,15 @@
 #include <cctype>
 #include <chrono>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
+#include <functional>
 #include <iomanip>
 #include <iostream>
+#include <memory>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "caar.h"
 #include "homme_caar.hpp"
@@ -49,7 +54,8 @@ void usage() {
             << "|  --tinman-dump-res=val     : whether to dump results to file (default=no)|\n"
             << "|  --tinman-num-exec=N       : number of times to execute (default=1)      |\n"
             << "|  --tinman-update-levels=val: rotate time levels between runs (default=no)|\n"
-            << "|  --tinman-device=N         : HIP device to run on (default=0)            |\n"
+            << "|  --tinman-device=N         : first HIP device to run on (default=0)      |\n"
+            << "|  --tinman-num-devices=N    : shard the elements over N GPUs (default=1)  |\n"
             << "|  --tinman-help             : prints this message                         |\n"
             << "+--------------------------------------------------------------------------+\n";
 }
@@ -59,7 +65,7 @@ void usage() {
 int main(int argc, char** argv) {
   using namespace Homme;
   bool dump_res = false, update_levels = false;
-  int num_exec = 1, device = 0;
+  int num_exec = 1, device = 0, num_devices = 1;
 
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
@@ -79,6 +85,8 @@ int main(int argc, char** argv) {
       num_exec = std::atoi(val);
     } else if (starts_with(a, "--tinman-device=")) {
       device = std::atoi(val);
+    } else if (starts_with(a, "--tinman-num-devices=")) {
+      num_devices = std::atoi(val);
     } else if (starts_with(a, "--tinman-dump-res=")) {
       if (!parse_yes_no(a, val, &dump_res)) return 1;
     } else if (starts_with(a, "--tinman-update-levels=")) {
@@ -102,34 +110,75 @@ int main(int argc, char** argv) {
   data.init_data();
   print_results_2norm(data);
 
-  std::cout << " --- Uploading " << num_elems << " elements to HIP device " << device << "...\n";
-  DeviceSession gpu(data, num_elems, device);
-  real n[3];
-  gpu.state_norms(data, n);
-  std::cout << "   ---> Norms (device):\n"
-            << "          ||v||_2  = " << std::setprecision(17) << n[0] << "\n"
-            << "          ||T||_2  = " << std::setprecision(17) << n[1] << "\n"
-            << "          ||dp||_2 = " << std::setprecision(17) << n[2] << "\n";
+  // Element sharding: contiguous slabs, one DeviceSession (context + stream)
+  // and one host thread per GPU, no exchange between them.
+  if (num_devices < 1 || num_devices > num_elems) num_devices = 1;
+  const int ndev = caar_device_count();
+  if (ndev < 1) {
+    std::cerr << "No HIP device is visible: the MI355X path cannot run (there is no CPU fallback).\n";
+    return 1;
+  }
+  if (num_devices > ndev)
+    std::cout << " --- note: " << num_devices << " shards on " << ndev << " device(s): shards share GPUs\n";
+  struct Shard {
+    int first, count, device;
+    TestData view;  // same host arrays, Control::nets/nete local to the slab
+    std::unique_ptr<DeviceSession> gpu;
+    real norms[3];
+  };
+  std::vector<Shard> shards(num_devices);
+  const int per = (num_elems + num_devices - 1) / num_devices;
+  for (int s = 0; s < num_devices; ++s) {
+    Shard& sh = shards[s];
+    sh.first = s * per < num_elems ? s * per : num_elems;
+    sh.count = (sh.first + per <= num_elems ? per : num_elems - sh.first);
+    sh.device = (device + s) % ndev;  // more shards than GPUs: they share devices (rehearsal only)
+    sh.view = data;
+    sh.view.control.nets = 0;
+    sh.view.control.nete = sh.count;
+  }
+  auto on_all = [&](const std::function<void(Shard&)>& f) {
+    std::vector<std::thread> th;
+    for (Shard& sh : shards)
+      if (sh.count > 0) th.emplace_back([&f, &sh] { f(sh); });
+    for (std::thread& t : th) t.join();
+  };
+  auto print_device_norms = [&]() {
+    on_all([](Shard& sh) { sh.gpu->state_norms(sh.view, sh.norms); });
+    real sq[3] = {0, 0, 0};  // print_results_2norm adds squares over elements (P:388-396)
+    for (const Shard& sh : shards)
+      if (sh.count > 0)
+        for (int f = 0; f < 3; ++f) sq[f] += sh.norms[f] * sh.norms[f];
+    std::cout << "   ---> Norms (device):\n"
+              << "          ||v||_2  = " << std::setprecision(17) << std::sqrt(sq[0]) << "\n"
+              << "          ||T||_2  = " << std::setprecision(17) << std::sqrt(sq[1]) << "\n"
+              << "          ||dp||_2 = " << std::setprecision(17) << std::sqrt(sq[2]) << "\n";
+  };
+
+  std::cout << " --- Uploading " << num_elems << " elements to " << num_devices << " HIP device(s) starting at "
+            << device << "...\n";
+  on_all([&](Shard& sh) { sh.gpu.reset(new DeviceSession(data, sh.first, sh.count, sh.device)); });
+  print_device_norms();
 
   std::cout << " --- Performing computations... (" << num_exec << " executions of the main loop on "
             << num_elems << " elements)\n";
   const auto t0 = std::chrono::steady_clock::now();
-  for (int i = 0; i < num_exec; ++i) {
-    gpu.run(data);
-    if (update_levels && i + 1 < num_exec) data.update_time_levels();
-  }
-  gpu.sync();
+  on_all([&](Shard& sh) {
+    for (int i = 0; i < num_exec; ++i) {
+      sh.gpu->run(sh.view);
+      if (update_levels && i + 1 < num_exec) sh.view.update_time_levels();
+    }
+    sh.gpu->sync();
+  });
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (update_levels)
+    for (int i = 0; i + 1 < num_exec; ++i) data.update_time_levels();
   std::cout << "   ---> compute_and_apply_rhs execution total time: " << secs << " s  ("
             << double(num_elems) * num_exec / secs << " element-updates/s, kernel "
             << caar_kernel_name(np, nlev) << ")\n";
 
-  gpu.state_norms(data, n);
-  std::cout << "   ---> Norms (device):\n"
-            << "          ||v||_2  = " << std::setprecision(17) << n[0] << "\n"
-            << "          ||T||_2  = " << std::setprecision(17) << n[1] << "\n"
-            << "          ||dp||_2 = " << std::setprecision(17) << n[2] << "\n";
-  gpu.download(data);
+  print_device_norms();
+  on_all([&](Shard& sh) { sh.gpu->download(sh.view); });
   print_results_2norm(data);
 
   if (dump_res) {

@@ -36,7 +36,9 @@ CaarDims dims_for(int ne) {
   return d;
 }
 
-CaarArrays host_arrays(const Arrays& a) {
+CaarArrays host_arrays(const Arrays& a, int first_elem = 0);
+
+CaarArrays host_arrays(const Arrays& a, int first_elem) {
   CaarArrays h;
   h.elem_D = a.elem_D;
   h.elem_Dinv = a.elem_Dinv;
@@ -54,6 +56,11 @@ CaarArrays host_arrays(const Arrays& a) {
   h.elem_derived_phi = a.elem_derived_phi;
   h.elem_derived_pecnd = a.elem_derived_pecnd;
   h.elem_derived_vn0 = a.elem_derived_vn0;
+  if (first_elem > 0) {  // element-major arrays: a slab starts first_elem * (doubles per element) in
+    const CaarDims one = dims_for(1);
+    double** p = reinterpret_cast<double**>(&h);
+    for (int i = 0; i < CAAR_NUM_ARRAYS; ++i) p[i] += (long long)first_elem * caar_array_len(&one, i);
+  }
   return h;
 }
 
@@ -80,7 +87,11 @@ CaarParams params_for(const TestData& d) {
 }  // namespace
 
 // ----------------------------------------------------------------- DeviceSession
-DeviceSession::DeviceSession(const TestData& data, int ne, int device) : ctx_(nullptr), num_elems_(ne) {
+DeviceSession::DeviceSession(const TestData& data, int ne, int device)
+    : DeviceSession(data, 0, ne, device) {}
+
+DeviceSession::DeviceSession(const TestData& data, int first_elem, int ne, int device)
+    : ctx_(nullptr), num_elems_(ne), first_elem_(first_elem) {
   const CaarDims d = dims_for(ne);
   if (!caar_supported(d.np, d.nlev)) check(CAAR_EUNSUPPORTED, "caar_supported(np, nlev)");
   check(caar_create(&ctx_, &d, device), "caar_create");
@@ -90,7 +101,7 @@ DeviceSession::DeviceSession(const TestData& data, int ne, int device) : ctx_(nu
 DeviceSession::~DeviceSession() { caar_destroy(ctx_); }
 
 void DeviceSession::upload(const TestData& data) {
-  const CaarArrays h = host_arrays(data.arrays);
+  const CaarArrays h = host_arrays(data.arrays, first_elem_);
   check(caar_upload(ctx_, &h, 0, num_elems_), "caar_upload");
 }
 
@@ -102,7 +113,7 @@ void DeviceSession::run(const TestData& data) {
 void DeviceSession::sync() { check(caar_sync(ctx_), "caar_sync"); }
 
 void DeviceSession::download(TestData& data, bool all_arrays) {
-  const CaarArrays h = host_arrays(data.arrays);
+  const CaarArrays h = host_arrays(data.arrays, first_elem_);
   check(caar_download(ctx_, &h, 0, num_elems_, all_arrays ? 1 : 0), "caar_download");
   sync();
 }

@@ -35,6 +35,10 @@ class DeviceSession {
  public:
   // uploads all 16 arrays of `data` (num_elems elements) to HIP device `device`
   explicit DeviceSession(const TestData& data, int num_elems, int device = 0);
+  // the same for the slab [first_elem, first_elem + num_elems) of data's arrays: one session
+  // per GPU when the element range is sharded (elements are independent: no exchange).
+  // run()/state_norms() then take Control::nets/nete relative to the slab.
+  DeviceSession(const TestData& data, int first_elem, int num_elems, int device);
   ~DeviceSession();
   DeviceSession(const DeviceSession&) = delete;
   DeviceSession& operator=(const DeviceSession&) = delete;
@@ -55,6 +59,7 @@ class DeviceSession {
  private:
   CaarContext* ctx_;
   int num_elems_;
+  int first_elem_;
 };
 
 }  // namespace Homme
