@@ -199,11 +199,6 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   // ---- phase 3: level-local tendencies and update, top level of the wave first ----------
   double below = 0.0;  // hydrostatic sum over the waves below this one, bottom-up (P:293,302)
   for (int w2 = WAVES - 1; w2 > w; --w2) below += s_tot_ht[w2 * PP + pt];
-  const M22 Dinv = load_m22(s_geo + G_DINV, pt);
-  const M22 Dm = load_m22(s_geo + G_D, pt);
-  const double fcor = s_geo[G_FCOR + pt];
-  const double spheremp = s_geo[G_SPHEREMP + pt];
-  const double phis = s_geo[G_PHIS + pt];
   const double eta_zero = k.eta_ave_w * 0.0;  // eta_dot_dpdn_tmp == 0 (P:22,172)
 
   double run_dp = base_dp, suml = base_div, run_ht = 0.0;
@@ -213,6 +208,12 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     LevelIn nxt = cur;
     if (r + 1 < TPW) nxt = load_level(r + 1);
 
+    // The metric terms are re-read from LDS at every level instead of living in 26 registers
+    // for the whole phase; the empty asm makes the pointer opaque so the loads are not hoisted.
+    const double* geo = s_geo;
+    asm volatile("" : "+v"(geo));
+    const M22 Dinv = load_m22(geo + G_DINV, pt);
+    const double phis = geo[G_PHIS + pt];
     const double dpr = park_rd[r * PP], ur = park_rd[BLK + r * PP], vr = park_rd[2 * BLK + r * PP];
     const double Tr = RELOAD_T ? cur.Tn0 : T[RELOAD_T ? 0 : r];
 
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     const double ckk = 0.5 * rp, ckl = rp;                             // P:333-334
     const double om = vgrad_p * rp - ckl * suml - ckk * divdp[r];      // P:325,336,348
     suml += divdp[r];                                                  // P:339
+    const M22 Dm = load_m22(geo + G_D, pt);
     const double vort = vorticity_sphere<COEF_LDS>(c, lane, Dm, rmetdet, rrearth, ur, vr);  // P:122
 
     const double Ephi = 0.5 * (ur * ur + vr * vr) + phi + cur.pec;  // P:196
@@ -240,6 +242,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     const double gpterm = Tv[r] * rp;                                  // P:219
     const double glnps1 = k.Rgas * gpterm * gp0;                       // P:221
     const double glnps2 = k.Rgas * gpterm * gp1;                       // P:222
+    const double fcor = geo[G_FCOR + pt], spheremp = geo[G_SPHEREMP + pt];
     const double vtens1 = vr * (fcor + vort) - gE0 - glnps1;         // P:227
     const double vtens2 = -ur * (fcor + vort) - gE1 - glnps2;        // P:228
     const double ttens = -vgrad_T + k.kappa * Tv[r] * om;              // P:230
