@@ -205,29 +205,31 @@ def test_bad_arguments_are_refused():
         tsa.compute_and_apply_rhs(cpu)  # no CPU fallback
 
 
-def test_full_size_properties():
-    """BASELINE.json configs[1]: NP=4, NLEV=72, 10 000 elements.  Size-independent
-    checks: (a) every element is processed independently, so elements i and j built
-    from the same inputs give bit-identical outputs wherever they sit in the grid;
-    (b) the first 3 elements equal the 3-element golden case; (c) idempotence of
-    the np1 state under a second call."""
-    E = 10000
-    data = tsa.TestData().init_data(E, 4, 72, device="cuda")
-    # make elements 5000.. copies of elements 0..4999's inputs? the closed form
-    # depends on ie, so instead overwrite element E-1 and 4321 with element 1's inputs
-    for n in tsa.ARRAY_NAMES:
+@pytest.mark.parametrize("np_,nlev,E,gold_name", [(4, 72, 10000, "np4_nlev72_closed"),
+                                                  (4, 128, 12500, "np4_nlev128_closed"),
+                                                  (8, 72, 20000, "np8_nlev72_closed")])
+def test_full_size_properties(np_, nlev, E, gold_name):
+    """BASELINE.json's full single-GPU sizes (configs[1]; one GPU's share of configs[2]/[3];
+    configs[4]).  Size-independent checks: (a) elements are processed independently, so
+    copies of one element's inputs give bit-identical outputs wherever they sit in the
+    grid; (b) the first elements equal the committed reference outputs of the small
+    closed-form case; (c) a second call reproduces the np1 state bit for bit."""
+    data = tsa.TestData().init_data(E, np_, nlev, device="cuda")
+    for n in tsa.ARRAY_NAMES:  # the closed form depends on ie: plant copies of element 1
         data.arrays[n][E - 1] = data.arrays[n][1]
-        data.arrays[n][4321] = data.arrays[n][1]
+        data.arrays[n][E // 2 + 77] = data.arrays[n][1]
     tsa.compute_and_apply_rhs(data)
     torch.cuda.synchronize()
     for n in tsa.caar.MUTATED:
         assert torch.equal(data.arrays[n][E - 1], data.arrays[n][1]), n
-        assert torch.equal(data.arrays[n][4321], data.arrays[n][1]), n
-    gold = cases.load_golden("np4_nlev72_closed")
-    sc = po.default_scalars(72)
-    got = {n: data.arrays[n][:3].cpu().numpy() for n in cases.OUTPUT_NAMES}
+        assert torch.equal(data.arrays[n][E // 2 + 77], data.arrays[n][1]), n
+    gold = cases.load_golden(gold_name)
+    ng = gold["elem_derived_phi"].shape[0]
+    sc = po.default_scalars(nlev)
+    got = {n: data.arrays[n][:ng].cpu().numpy() for n in cases.OUTPUT_NAMES}
     check_outputs(got, gold, sc, "full-size/golden")
-    snap = {n: data.arrays[n].clone() for n in ("elem_state_v", "elem_state_T", "elem_state_dp3d", "elem_derived_phi")}
+    keep = ("elem_state_v", "elem_state_T", "elem_state_dp3d", "elem_derived_phi")
+    snap = {n: data.arrays[n].clone() for n in keep}
     tsa.compute_and_apply_rhs(data)
     torch.cuda.synchronize()
     for n, t in snap.items():
