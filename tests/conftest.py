@@ -17,3 +17,16 @@ def pytest_configure(config):
 def oracle():
     from oracle import pyoracle as po
     return po.Oracle()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_artifacts():
+    """A clean checkout has no binaries (they are git-ignored): build the HIP library, the
+    C++ host side and the C oracle once per session.  hipcc cross-compiles without a GPU."""
+    from tinman_sandbox_amd import build as b
+    from oracle import pyoracle as po
+    if not os.path.exists(b.LIB) or not os.path.exists(os.path.join(ROOT, "tinman_sandbox_amd", "host", "caar_driver")):
+        b.build_all()
+    if not os.path.exists(os.path.join(ROOT, "oracle", "libcaar_oracle.so")):
+        po.build(ref=False)
+    yield
