@@ -11,5 +11,6 @@ test-gpu: build
 bench: build
 	python bench.py
 clean:
-	rm -f tinman_sandbox_amd/csrc/*.so tinman_sandbox_amd/host/*.so tinman_sandbox_amd/host/caar_driver*[!p]
+	rm -f tinman_sandbox_amd/csrc/*.so tinman_sandbox_amd/host/*.so tinman_sandbox_amd/host/caar_driver \
+	      tinman_sandbox_amd/host/caar_driver_np4_nlev128 tinman_sandbox_amd/host/caar_driver_np8_nlev72
 	$(MAKE) -C oracle clean
