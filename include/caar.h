@@ -195,6 +195,10 @@ int caar_upload(CaarContext *ctx, const CaarArrays *host, int e0, int e1);
 /* Device -> host copy of the arrays the path mutates (state_v/T/dp3d, eta_dot_dpdn,
  * omega_p, phi, vn0) for elements [e0, e1); all_arrays != 0 copies all 16. */
 int caar_download(CaarContext *ctx, const CaarArrays *host, int e0, int e1, int all_arrays);
+/* The same two copies for a Fortran host: `f90_host` points to HOST arrays in Fortran order
+ * (see "Fortran-layout ingest / egress" above); the re-layout happens on the device. */
+int caar_upload_f90(CaarContext *ctx, const CaarArrays *f90_host, int e0, int e1);
+int caar_download_f90(CaarContext *ctx, const CaarArrays *f90_host, int e0, int e1, int all_arrays);
 /* Enqueue one compute_and_apply_rhs on the context's device arrays
  * (params->Dvv is read from host memory and cached on the device). */
 int caar_run(CaarContext *ctx, const CaarParams *params);

@@ -64,6 +64,29 @@ def test_driver_shards_elements_over_devices():
     assert np.allclose(blocks[3], after, rtol=1e-13, atol=0)
 
 
+def test_fortran_host_prints_the_reference_fortran_norms():
+    """A Fortran program (host/fortran/caar_f90_driver.F90) with the reference Fortran driver's
+    flow and single-precision Dvv literals, calling the library through caar_mod
+    (iso_c_binding) on Fortran-ordered arrays: it must print the norms the reference's own
+    Fortran executable prints (tests/golden/fortran_orig_stdout.txt) and the first entries
+    of the reference's golden vectors Ttest / v1test (test_mod.F90)."""
+    from tinman_sandbox_amd import build
+    exe = build.build_fortran_driver()
+    if exe is None:
+        pytest.skip("flang not available")
+    out = subprocess.run([exe, "3"], check=True, capture_output=True, text=True, timeout=300).stdout
+    got = [float(x) for x in re.findall(r"\|\|(?:v|T|dp)\|\|_2\s*=\s*([-+0-9.eE]+)", out)]
+    txt = open(os.path.join(cases.GOLDEN_DIR, "fortran_orig_stdout.txt")).read().split()
+    want = [float(txt[i + 2]) for i, w in enumerate(txt) if w.startswith("||")]
+    assert len(got) == 6 and len(want) == 6, out
+    assert np.allclose(got[:3], want[:3], rtol=1e-15, atol=0)
+    assert np.allclose(got[3:], want[3:], rtol=1e-13, atol=0)
+    with np.load(os.path.join(cases.GOLDEN_DIR, "fortran_test_mod_vectors.npz")) as z:
+        T0, v0 = float(z["Ttest"][0]), float(z["v1test"][0])
+    spot = [float(x) for x in re.findall(r"np1,1\)\s*=\s*([-+0-9.eE]+)", out)]
+    assert abs(spot[0] - T0) <= 1e-12 * abs(T0) and abs(spot[1] - v0) <= 1e-12 * abs(v0), (spot, T0, v0)
+
+
 def test_reference_main_links_against_the_hip_path():
     exe = os.path.join(ROOT, "oracle", "_ref", "pointers_only_hip")
     if not os.path.exists(exe):

@@ -70,10 +70,33 @@ def build_host_driver(force=False, verbose=False, np_=4, nlev=72):
     return exe
 
 
+FLANG = "/opt/rocm/lib/llvm/bin/flang"
+
+
+def build_fortran_driver(force=False, verbose=False):
+    """Fortran host example (host/fortran/): caar_mod (iso_c_binding interface) + a driver with
+    the reference Fortran driver's flow, linked against libcaar_hip.so.  Needs flang (ROCm)."""
+    fdir = os.path.join(HOST, "fortran")
+    if not os.path.exists(FLANG):
+        return None
+    out = os.path.join(fdir, "build")
+    exe = os.path.join(out, "caar_f90_driver")
+    srcs = [os.path.join(fdir, "caar_mod.F90"), os.path.join(fdir, "caar_f90_driver.F90")]
+    if force or _stale(exe, srcs + [LIB]):
+        os.makedirs(out, exist_ok=True)
+        cmd = [FLANG, "-O2", "-module-dir", out] + srcs + ["-L" + CSRC, "-lcaar_hip", "-Wl,-rpath," + CSRC,
+                                                             "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=out, capture_output=not verbose)
+    return exe
+
+
 def build_all(force=False, verbose=False):
     lib = build_library(force, verbose)
     for np_, nlev in ((4, 72), (4, 128), (8, 72)):
         build_host_driver(force, verbose, np_, nlev)
+    build_fortran_driver(force, verbose)
     return lib
 
 

@@ -60,7 +60,7 @@ class CaarLibrary:
     SYMBOLS = ("caar_supported", "caar_abi_version", "caar_device_count", "caar_strerror", "caar_array_len",
                "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator", "caar_reciprocal",
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
-               "caar_variant_info", "caar_set_xcd_chunked", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_traffic_skeleton", "caar_create", "caar_destroy", "caar_upload", "caar_download",
+               "caar_variant_info", "caar_set_xcd_chunked", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_traffic_skeleton", "caar_create", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_download_f90",
                "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
                "caar_time_runs")
 
@@ -106,6 +106,8 @@ class CaarLibrary:
         L.caar_destroy.restype = None
         L.caar_upload.argtypes = [vp, C.POINTER(_CaarArrays), C.c_int, C.c_int]
         L.caar_download.argtypes = [vp, C.POINTER(_CaarArrays), C.c_int, C.c_int, C.c_int]
+        L.caar_upload_f90.argtypes = [vp, C.POINTER(_CaarArrays), C.c_int, C.c_int]
+        L.caar_download_f90.argtypes = [vp, C.POINTER(_CaarArrays), C.c_int, C.c_int, C.c_int]
         L.caar_run.argtypes = [vp, C.POINTER(_CaarParams)]
         L.caar_sync.argtypes = [vp]
         L.caar_device_arrays.argtypes = [vp, C.POINTER(_CaarArrays)]

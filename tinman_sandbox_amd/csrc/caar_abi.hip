@@ -72,12 +72,14 @@ struct CaarContext {
   double dvv_host[64];  // last uploaded Dvv (re-upload only when it changes)
   bool dvv_valid;
   double* norms_dev;    // 3 * num_elems
+  double* stage_dev;    // staging for Fortran-ordered host arrays (largest array), lazily allocated
 };
 
 static double** array_slot(CaarArrays* a, int i) { return reinterpret_cast<double**>(a) + i; }
 static double* const* array_slot(const CaarArrays* a, int i) {
   return reinterpret_cast<double* const*>(a) + i;
 }
+static int array_ncomp(int i);
 // the arrays compute_and_apply_rhs writes (SURVEY.md 8b "mutated in place")
 static const int kMutated[] = {6, 7, 8, 11, 12, 13, 15};
 
@@ -346,6 +348,7 @@ void caar_destroy(CaarContext* c) {
     if (*array_slot(&c->dev, i)) (void)hipFree(*array_slot(&c->dev, i));
   if (c->dvv_dev) (void)hipFree(c->dvv_dev);
   if (c->norms_dev) (void)hipFree(c->norms_dev);
+  if (c->stage_dev) (void)hipFree(c->stage_dev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -386,6 +389,50 @@ int caar_download(CaarContext* c, const CaarArrays* host, int e0, int e1, int al
     }
   }
   return CAAR_OK;
+}
+
+// Fortran-ordered HOST arrays <-> the context's device arrays: each array goes through one
+// device staging buffer (H2D copy + layout kernel, or layout kernel + D2H copy), all ordered
+// on the context stream, so the staging buffer is reused array after array.
+static int f90_transfer(CaarContext* c, const CaarArrays* f90_host, int e0, int e1, bool upload, bool mutated_only) {
+  if (!c || !f90_host || e0 < 0 || e1 > c->dims.num_elems || e0 > e1) return CAAR_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->stage_dev) {
+    long long biggest = 0;
+    for (int i = 0; i < CAAR_NUM_ARRAYS; ++i)
+      if (caar_array_len(&c->dims, i) > biggest) biggest = caar_array_len(&c->dims, i);
+    hipError_t e = hipMalloc((void**)&c->stage_dev, sizeof(double) * (size_t)biggest);
+    if (e != hipSuccess) return e == hipErrorOutOfMemory ? CAAR_ENOMEM : (int)e;
+  }
+  for (int i = 0; i < CAAR_NUM_ARRAYS; ++i) {
+    bool wanted = !mutated_only;
+    for (int m : kMutated) wanted = wanted || m == i;
+    if (!wanted) continue;
+    double* h = *array_slot(f90_host, i);
+    if (!h) return CAAR_EINVAL;
+    const long long per = caar_array_len(&c->dims, i) / c->dims.num_elems;
+    const size_t off = (size_t)per * e0, n = (size_t)per * (e1 - e0);
+    if (n == 0) continue;
+    double* d = *array_slot(&c->dev, i) + off;
+    if (upload) {
+      HIP_TRY(hipMemcpyAsync(c->stage_dev, h + off, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(caar::launch_layout(d, c->stage_dev, n, c->dims.np, array_ncomp(i), c->dims.nlev, c->dims.qsize_d,
+                                  i == 10, true, c->stream));
+    } else {
+      HIP_TRY(caar::launch_layout(c->stage_dev, d, n, c->dims.np, array_ncomp(i), c->dims.nlev, c->dims.qsize_d,
+                                  i == 10, false, c->stream));
+      HIP_TRY(hipMemcpyAsync(h + off, c->stage_dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    }
+  }
+  return CAAR_OK;
+}
+
+int caar_upload_f90(CaarContext* c, const CaarArrays* f90_host, int e0, int e1) {
+  return f90_transfer(c, f90_host, e0, e1, true, false);
+}
+
+int caar_download_f90(CaarContext* c, const CaarArrays* f90_host, int e0, int e1, int all_arrays) {
+  return f90_transfer(c, f90_host, e0, e1, false, !all_arrays);
 }
 
 int caar_run(CaarContext* c, const CaarParams* p) {
