@@ -137,6 +137,60 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64) void traffic_skeleton_np4(cons
   if (tid < PP) eta_last[ulane] = eta_last[ulane] + 0.0;
 }
 
+// Same bytes as traffic_skeleton_np4<NLEV, 2, ...> but every access 16 bytes per lane: the two
+// tiles of a wave are contiguous (128 doubles of a scalar field = one dwordx4 per lane; 256
+// doubles of v = two).  Probes whether wider accesses alone raise the ceiling.
+template <int NLEV, int POL>
+__global__ __launch_bounds__(NLEV / 8 * 64) void traffic_skeleton_np4_w16(const KernelArgs k) {
+  constexpr int PP = 16, BLK = NLEV * PP;
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63, pt = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned ulane = lane;
+  const long long ie_s = element_of_block(k, blockIdx.x);
+  if (ie_s < 0) return;
+  const size_t ie = (size_t)ie_s, tl = (size_t)k.timelevels, wb = (size_t)w * 128;
+  auto S = [&](const double* base) { return reinterpret_cast<const v2*>(base + wb); };
+  auto SW = [&](double* base) { return reinterpret_cast<v2*>(base + wb); };
+  const v2* dp_n0 = S(k.dp3d + (ie * tl + k.n0) * BLK);
+  const v2* T_n0 = S(k.T + (ie * tl + k.n0) * BLK);
+  const v2* Qdp = S(k.Qdp + ((ie * k.qsize_d + 0) * 2 + (k.qn0 >= 0 ? k.qn0 : 0)) * BLK);
+  const v2* T_nm1 = S(k.T + (ie * tl + k.nm1) * BLK);
+  const v2* dp_nm1 = S(k.dp3d + (ie * tl + k.nm1) * BLK);
+  const v2* pecnd = S(k.pecnd + ie * BLK);
+  v2* omega_p = SW(k.omega_p + ie * BLK);
+  v2* phi = SW(k.phi + ie * BLK);
+  v2* eta = SW(k.eta_dot_dpdn + ie * (BLK + PP));
+  v2* T_np1 = SW(k.T + (ie * tl + k.np1) * BLK);
+  v2* dp_np1 = SW(k.dp3d + (ie * tl + k.np1) * BLK);
+  const v2* v_n0 = reinterpret_cast<const v2*>(k.v + ((ie * tl + k.n0) * BLK + wb) * 2);
+  const v2* v_nm1 = reinterpret_cast<const v2*>(k.v + ((ie * tl + k.nm1) * BLK + wb) * 2);
+  v2* v_np1 = reinterpret_cast<v2*>(k.v + ((ie * tl + k.np1) * BLK + wb) * 2);
+  v2* vn0 = reinterpret_cast<v2*>(k.vn0 + (ie * BLK + wb) * 2);
+  double* eta_last = k.eta_dot_dpdn + ie * (BLK + PP) + BLK;
+  double g = k.fcor[ie * PP + pt] + k.spheremp[ie * PP + pt] + k.metdet[ie * PP + pt] +
+             k.rmetdet[ie * PP + pt] + k.phis[ie * PP + pt];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) g += k.D[(ie * PP + pt) * 4 + j] + k.Dinv[(ie * PP + pt) * 4 + j];
+  g *= 0.0;
+  const v2 a = ld<POL>(dp_n0 + ulane) + ld<POL>(T_n0 + ulane) + ld<POL>(Qdp + ulane) + ld<POL>(pecnd + ulane) + g;
+  const v2 uv0 = ld<POL>(v_n0 + ulane), uv1 = ld<POL>(v_n0 + 64 + ulane);
+  const v2 um0 = ld<POL>(v_nm1 + ulane), um1 = ld<POL>(v_nm1 + 64 + ulane);
+  const v2 un0 = ld<POL>(vn0 + ulane), un1 = ld<POL>(vn0 + 64 + ulane);
+  const v2 tn = ld<POL>(T_nm1 + ulane), dn = ld<POL>(dp_nm1 + ulane), om = ld<POL>(omega_p + ulane),
+           et = ld<POL>(eta + ulane);
+  st<POL>(v_np1 + ulane, uv0 + um0);
+  st<POL>(v_np1 + 64 + ulane, uv1 + um1);
+  st<POL>(T_np1 + ulane, tn + a);
+  st<POL>(dp_np1 + ulane, dn + a);
+  st<POL>(phi + ulane, a);
+  st<POL>(omega_p + ulane, om + a * 0.0);
+  st<POL>(vn0 + ulane, un0);
+  st<POL>(vn0 + 64 + ulane, un1);
+  st<POL>(eta + ulane, et + 0.0);
+  if (tid < PP) eta_last[ulane] = eta_last[ulane] + 0.0;
+}
+
 template <int NLEV, int TPW, int NTL, int NTS, bool AF>
 static void skel(const KernelArgs& k, int n, hipStream_t s) {
   hipLaunchKernelGGL((traffic_skeleton_np4<NLEV, TPW, NTL, NTS, AF>), dim3(k.per_xcd ? 8 * k.per_xcd : n), dim3(NLEV / 4 / TPW * 64), 0, s, k);
@@ -158,6 +212,8 @@ hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, i
       case 10: skel<72, 2, 2, 1, true>(k, num_elems, s); break;
       case 11: skel<72, 2, 1, 2, true>(k, num_elems, s); break;
       case 12: skel<72, 2, 2, 2, true>(k, num_elems, s); break;
+      case 13: hipLaunchKernelGGL((traffic_skeleton_np4_w16<72, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(576), 0, s, k); break;
+      case 14: hipLaunchKernelGGL((traffic_skeleton_np4_w16<72, 0>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(576), 0, s, k); break;
       default: return hipErrorInvalidValue;
     }
   } else if (nlev == 128) {
