@@ -152,6 +152,42 @@ def measure_config(tsa, torch, dev, np_, nlev, elems, steps, warmup):
             "kernel": tsa.library().lib.caar_kernel_name(np_, nlev).decode()}
 
 
+def measured_ceilings(tsa, torch, dev, np_, nlev, elems):
+    """What the memory system of THIS box delivers, next to the 8 TB/s spec peak (BASELINE.md
+    section 3): a plain 8 B/lane device copy, and the traffic skeleton — exactly the bytes and
+    addressing of the CAAR kernel with no arithmetic, non-temporal accesses."""
+    import ctypes as C
+    L = tsa.library()
+    st = torch.cuda.current_stream(dev)
+
+    def timed(fn, reps=10):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            fn()
+        e1.record(st)
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    n = 1 << 27
+    src = torch.ones(n, dtype=torch.float64, device=dev)
+    dst = torch.empty_like(src)
+    t = timed(lambda: L.check(L.lib.caar_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n, 8,
+                                                     C.c_void_p(st.cuda_stream)), "copy"))
+    out = {"stream_copy_GBs": 2 * n * 8 / t / 1e9}
+    del src, dst
+    if np_ == 4:
+        data = tsa.TestData().init_data(elems, np_, nlev, device=dev)
+        dims, ptrs, prm = data.arrays.dims(), data.arrays.pointers(), data.params()
+        t = timed(lambda: L.check(L.lib.caar_traffic_skeleton(C.byref(dims), C.byref(ptrs), C.byref(prm), 8,
+                                                              C.c_void_p(st.cuda_stream)), "skeleton"))
+        out["traffic_skeleton_GBs"] = tsa.algorithmic_bytes(np_, nlev) * elems / t / 1e9
+        del data
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -267,6 +303,9 @@ def main():
             torch.cuda.empty_cache()
             out["other_configs"] = [measure_config(tsa, torch, dev, 4, 128, 12500, 20, 3),
                                     measure_config(tsa, torch, dev, 8, 72, 20000, 10, 2)]
+        if world == 1 and not args.no_other_configs:
+            out["roofline"]["measured_on_this_box"] = measured_ceilings(tsa, torch, dev, args.np_, args.nlev,
+                                                                        args.elems_per_gpu)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.np_, args.nlev, args.cpu_seconds)
         print(json.dumps(out))
