@@ -160,3 +160,23 @@ def test_device_reciprocal_is_within_one_ulp():
     ulp = np.spacing(want)
     assert np.max(np.abs(got - want) / ulp) <= 1.0
     assert got[0] == 1.0 and got[1] == 0.5
+
+
+def test_four_time_levels(oracle):
+    """The layout's time-level count is a run-time dimension (the reference fixes 3,
+    config.h.in:7): four levels, path on levels (3, 0, 2)."""
+    arrs = cases.hashed_arrays(4, 72, 2, seed=81, timelevels=4)
+    sc = po.default_scalars(72)
+    sc.update(n0=3, np1=0, nm1=2, dt2=2.0)
+    Dvv = cases.dvv_for(4)
+    want = cases.copy_arrays(arrs)
+    oracle.compute_and_apply_rhs(want, Dvv, sc)
+    data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    assert data.arrays.timelevels == 4
+    tsa.compute_and_apply_rhs(data)
+    torch.cuda.synchronize()
+    got = data.arrays.to_numpy()
+    for n in tsa.caar.MUTATED:
+        assert cases.scaled_err(got[n], want[n]) <= 1e-12, n
+    for t in (1, 2, 3):
+        assert np.array_equal(got["elem_state_T"][:, t], arrs["elem_state_T"][:, t])
