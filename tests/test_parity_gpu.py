@@ -288,3 +288,19 @@ def test_randomised_controls_match_oracle(oracle):
             else:
                 assert np.array_equal(got[n][:sc["nets"]], arrs[n][:sc["nets"]]), (i, n)
                 assert np.array_equal(got[n][sc["nete"]:], arrs[n][sc["nete"]:]), (i, n)
+
+
+@pytest.mark.parametrize("nlev", [32, 60, 64, 80, 96])
+def test_other_level_counts_match_oracle(oracle, nlev):
+    """NP=4 level counts beyond the BASELINE configs (the reference builds any PLEV from
+    config.h.in:3).  No reference fixture exists for them: pinned through the oracle, which
+    is pinned bit-for-bit at NLEV 72 and 128 with the same run-time-dimension code."""
+    assert tsa.library().lib.caar_supported(4, nlev)
+    arrs = cases.hashed_arrays(4, nlev, 3, seed=90 + nlev)
+    Dvv = cases.dvv_for(4)
+    sc = po.default_scalars(nlev)
+    sc.update(n0=1, np1=2, nm1=0, qn0=1, dt2=7.0, eta_ave_w=0.3, rrearth=1e-4)
+    want = cases.copy_arrays(arrs)
+    oracle.compute_and_apply_rhs(want, Dvv, sc)
+    _, got = run_gpu(arrs, Dvv, sc)
+    check_outputs(got, want, sc, "nlev%d" % nlev)

@@ -390,4 +390,12 @@ KernelVariant kNp4Nlev128[] = {
 };
 int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 
+// Other level counts HOMME configurations use (the reference builds any PLEV from config.h):
+// one launch shape each, same kernel template.
+KernelVariant kNp4Nlev32[] = {{"caar_np4_kernel<32, 2, 1, true, true, 1, false, false>", "4 waves x 2 tiles, nt", launch_np4<32, 2, 1, true, 1>}};
+KernelVariant kNp4Nlev60[] = {{"caar_np4_kernel<60, 3, 1, true, true, 1, false, false>", "5 waves x 3 tiles, nt", launch_np4<60, 3, 1, true, 1>}};
+KernelVariant kNp4Nlev64[] = {{"caar_np4_kernel<64, 2, 1, true, true, 1, false, false>", "8 waves x 2 tiles, nt", launch_np4<64, 2, 1, true, 1>}};
+KernelVariant kNp4Nlev80[] = {{"caar_np4_kernel<80, 2, 1, true, true, 1, false, false>", "10 waves x 2 tiles, nt", launch_np4<80, 2, 1, true, 1>}};
+KernelVariant kNp4Nlev96[] = {{"caar_np4_kernel<96, 3, 1, true, true, 1, false, false>", "8 waves x 3 tiles, nt", launch_np4<96, 3, 1, true, 1>}};
+
 }  // namespace caar
