@@ -53,6 +53,16 @@ __device__ __forceinline__ void scan_up(double x, int lane, int sub, double& inc
   excl = sub <= 2 ? t : 0.0;
 }
 
+// Workgroup barrier.  __syncthreads() also drains the wave's global-memory counter
+// (s_waitcnt vmcnt(0)); in the persistent form that would stall every barrier on the previous
+// element's stores, so there only the LDS counter is drained — the barriers order LDS
+// traffic, all global data is wave-private.
+template <bool LDS_ONLY>
+__device__ __forceinline__ void wg_barrier() {
+  if constexpr (LDS_ONLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
+}
+
 // LDS image of the element's metric terms: 13 values per GLL point
 enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, G_D = 80, G_DINV = 144, G_SIZE = 208 };
 
@@ -114,8 +124,22 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
     return x;
   };
 
+  // address of the idx-th entry of an element's LDS metric image (G_* layout)
+  auto geo_src = [&](size_t ie, int idx) -> const double* {
+    if (idx < G_SPHEREMP) return k.fcor + ie * PP + idx;
+    if (idx < G_METDET) return k.spheremp + ie * PP + (idx - G_SPHEREMP);
+    if (idx < G_RMETDET) return k.metdet + ie * PP + (idx - G_METDET);
+    if (idx < G_PHIS) return k.rmetdet + ie * PP + (idx - G_RMETDET);
+    if (idx < G_D) return k.phis + ie * PP + (idx - G_PHIS);
+    if (idx < G_DINV) return k.D + ie * PP * 4 + (idx - G_D);
+    return k.Dinv + ie * PP * 4 + (idx - G_DINV);
+  };
+  static_assert(!PERSIST || THREADS >= G_SIZE, "persistent form stages one metric value per thread");
+
   // ---- phase 0: issue the n0 loads of the first element --------------------------------
   N0In in = load_n0((size_t)ie_s);
+  double geo_reg = 0.0;
+  if (PERSIST && tid < G_SIZE) geo_reg = *geo_src((size_t)ie_s, tid);
   if (tid < 16) s_dvv[tid] = k.Dvv[tid];
   RowCoef c;
   int par = 0;
@@ -169,19 +193,14 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
       for (int r = 0; r < TPW; ++r) pre[r] = load_tile(r);
     }
 
-    // stage the element's metric terms in LDS
-    for (int idx = tid; idx < G_SIZE; idx += THREADS) {
-      const double* src;
-      if (idx < G_SPHEREMP) src = k.fcor + ie * PP + idx;
-      else if (idx < G_METDET) src = k.spheremp + ie * PP + (idx - G_SPHEREMP);
-      else if (idx < G_RMETDET) src = k.metdet + ie * PP + (idx - G_METDET);
-      else if (idx < G_PHIS) src = k.rmetdet + ie * PP + (idx - G_RMETDET);
-      else if (idx < G_D) src = k.phis + ie * PP + (idx - G_PHIS);
-      else if (idx < G_DINV) src = k.D + ie * PP * 4 + (idx - G_D);
-      else src = k.Dinv + ie * PP * 4 + (idx - G_DINV);
-      s_geo[idx] = *src;
+    // stage the element's metric terms in LDS (PERSIST: the value was requested during the
+    // previous element's last phase, ahead of its stores)
+    if (PERSIST) {
+      if (tid < G_SIZE) s_geo[tid] = geo_reg;
+    } else {
+      for (int idx = tid; idx < G_SIZE; idx += THREADS) s_geo[idx] = *geo_src(ie, idx);
     }
-    __syncthreads();  // also fences the previous element's last reads of the tile totals
+    wg_barrier<PERSIST>();  // also fences the previous element's last reads of the tile totals
 
     if (first) {
       c = make_row_coef(s_dvv, lane);
@@ -211,7 +230,7 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
         s_tot_div[t * PP + pt] = in_div;
       }
     }
-    __syncthreads();
+    wg_barrier<PERSIST>();
 
     // ---- phase 2: p, running divdp sum, hydrostatic increments and their in-tile scan --
     double p[TPW], rp[TPW], suml[TPW], ex_ht[TPW];
@@ -243,7 +262,7 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
     TileIn cur = PF ? pre[TPW - 1] : load_tile(TPW - 1);  // in flight across the barrier
     double l_eta_last = 0.0;
     if (tid < PP) l_eta_last = eta_last[ulane];
-    __syncthreads();
+    wg_barrier<PERSIST>();
 
     // PERSIST: request the next element's n0 inputs now; they land while phase 3 computes
     N0In nxt_in;
@@ -253,6 +272,7 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
       if (eb_next < (unsigned)k.nelem) {
         nxt_ie = (long long)k.nets + eb_next;
         nxt_in = load_n0((size_t)nxt_ie);
+        if (tid < G_SIZE) geo_reg = *geo_src((size_t)nxt_ie, tid);
       }
       eb = eb_next;
     }
