@@ -28,7 +28,7 @@
 namespace caar {
 
 
-template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T>
+template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T, bool BATCH>
 __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const KernelArgs k) {
   using namespace np8;
   constexpr int WAVES = NLEV / TPW;
@@ -38,7 +38,8 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
 
   __shared__ __attribute__((aligned(16))) double s_dvvT[64];
   __shared__ __attribute__((aligned(16))) double s_geo[G_SIZE];
-  __shared__ __attribute__((aligned(16))) double s_tile[WAVES * 64];
+  constexpr int SLOTS = BATCH ? 5 : 1;  // LDS tile slots per wave (BATCH: p, T, Ephi, vcov1, vcov0)
+  __shared__ __attribute__((aligned(16))) double s_tile[WAVES * 64 * SLOTS];
   __shared__ double s_park[3 * BLK];        // dp, u, v of every level, [field][lev][pt]
   __shared__ double s_tot_dp[WAVES * PP];   // per wave: sum of dp over its levels
   __shared__ double s_tot_div[WAVES * PP];  // ... of divdp
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   __syncthreads();
 
   Ctx c;
-  c.tile = s_tile + w * 64;
+  c.tile = s_tile + w * 64 * SLOTS;
   c.a = lane >> 3;
   c.b = lane & 7;
   c.dvvT = s_dvvT;
@@ -124,7 +125,18 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     for (int r = 0; r < TPW; ++r) {
       const N0In x = ring[r % PD];
       if (r + PD < TPW) ring[r % PD] = load_n0(r + PD);
-      divdp[r] = divergence_sphere<COEF_LDS>(c, lane, Dinv, metdet, rmetdet, rrearth, x.uv.x * x.dp, x.uv.y * x.dp);  // P:114-121
+      if (BATCH) {  // both contravariant components go to their slots, one LDS round trip
+        const double vdp0 = x.uv.x * x.dp, vdp1 = x.uv.y * x.dp;                     // P:114-115
+        const double gv0 = metdet * (Dinv.m00 * vdp0 + Dinv.m01 * vdp1);             // S:66-67
+        const double gv1 = metdet * (Dinv.m10 * vdp0 + Dinv.m11 * vdp1);             // S:68-69
+        wave_lds_fence();
+        c.tile[lane] = gv0;
+        c.tile[64 + lane] = gv1;
+        wave_lds_fence();
+        divdp[r] = (d_da_slot<COEF_LDS>(c, 0) + d_db_slot<COEF_LDS>(c, 1)) * rmetdet * rrearth;  // S:81-85
+      } else {
+        divdp[r] = divergence_sphere<COEF_LDS>(c, lane, Dinv, metdet, rmetdet, rrearth, x.uv.x * x.dp, x.uv.y * x.dp);  // P:114-121
+      }
       if (!RELOAD_T) T[r] = x.T;
       Tv[r] = MOIST ? x.T * (1.0 + k.rv_over_rd_m1 * (x.q * recip(x.dp))) : x.T;  // P:135,150-151
       run_dp += x.dp;
@@ -225,20 +237,42 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     // levels below r inside this wave = wave total - inclusive prefix (P:302's phii)
     const double phi = (phis + (below + (wave_ht - run_ht))) + 0.5 * ht;  // P:303,309
 
-    double gp0, gp1;
-    gradient_sphere<COEF_LDS>(c, lane, Dinv, rrearth, p, gp0, gp1);              // P:103
-    const double vgrad_p = ur * gp0 + vr * gp1;                    // P:111
+    const M22 Dm = load_m22(geo + G_D, pt);
+    const double Ephi = 0.5 * (ur * ur + vr * vr) + phi + cur.pec;     // P:196
+    double gp0, gp1, gT0, gT1, gE0, gE1, vort;
+    if (BATCH) {
+      // all five fields of the level go to their LDS slots, then every contraction reads:
+      // one LDS round trip per level instead of one per operator
+      const double vc0 = Dm.m00 * ur + Dm.m10 * vr;                    // S:106-107
+      const double vc1 = Dm.m01 * ur + Dm.m11 * vr;                    // S:108-109
+      wave_lds_fence();
+      c.tile[lane] = p;
+      c.tile[64 + lane] = Tr;
+      c.tile[128 + lane] = Ephi;
+      c.tile[192 + lane] = vc1;
+      c.tile[256 + lane] = vc0;
+      wave_lds_fence();
+      const double pa = d_da_slot<COEF_LDS>(c, 0) * rrearth, pb = d_db_slot<COEF_LDS>(c, 0) * rrearth;  // S:34-35
+      gp0 = Dinv.m00 * pa + Dinv.m10 * pb;                             // S:43-47
+      gp1 = Dinv.m01 * pa + Dinv.m11 * pb;
+      const double ta = d_da_slot<COEF_LDS>(c, 1) * rrearth, tb = d_db_slot<COEF_LDS>(c, 1) * rrearth;
+      gT0 = Dinv.m00 * ta + Dinv.m10 * tb;
+      gT1 = Dinv.m01 * ta + Dinv.m11 * tb;
+      const double ea = d_da_slot<COEF_LDS>(c, 2) * rrearth, eb = d_db_slot<COEF_LDS>(c, 2) * rrearth;
+      gE0 = Dinv.m00 * ea + Dinv.m10 * eb;
+      gE1 = Dinv.m01 * ea + Dinv.m11 * eb;
+      vort = (d_da_slot<COEF_LDS>(c, 3) - d_db_slot<COEF_LDS>(c, 4)) * rmetdet * rrearth;  // S:121-125
+    } else {
+      gradient_sphere<COEF_LDS>(c, lane, Dinv, rrearth, p, gp0, gp1);    // P:103
+      vort = vorticity_sphere<COEF_LDS>(c, lane, Dm, rmetdet, rrearth, ur, vr);  // P:122
+      gradient_sphere<COEF_LDS>(c, lane, Dinv, rrearth, Tr, gT0, gT1);   // P:200
+      gradient_sphere<COEF_LDS>(c, lane, Dinv, rrearth, Ephi, gE0, gE1); // P:213
+    }
+    const double vgrad_p = ur * gp0 + vr * gp1;                        // P:111
     const double ckk = 0.5 * rp, ckl = rp;                             // P:333-334
     const double om = vgrad_p * rp - ckl * suml - ckk * divdp[r];      // P:325,336,348
     suml += divdp[r];                                                  // P:339
-    const M22 Dm = load_m22(geo + G_D, pt);
-    const double vort = vorticity_sphere<COEF_LDS>(c, lane, Dm, rmetdet, rrearth, ur, vr);  // P:122
-
-    const double Ephi = 0.5 * (ur * ur + vr * vr) + phi + cur.pec;  // P:196
-    double gT0, gT1, gE0, gE1;
-    gradient_sphere<COEF_LDS>(c, lane, Dinv, rrearth, Tr, gT0, gT1);           // P:200
-    const double vgrad_T = ur * gT0 + vr * gT1;                    // P:209
-    gradient_sphere<COEF_LDS>(c, lane, Dinv, rrearth, Ephi, gE0, gE1);           // P:213
+    const double vgrad_T = ur * gT0 + vr * gT1;                        // P:209
     const double gpterm = Tv[r] * rp;                                  // P:219
     const double glnps1 = k.Rgas * gpterm * gp0;                       // P:221
     const double glnps2 = k.Rgas * gpterm * gp1;                       // P:222
@@ -266,24 +300,26 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   if (tid < PP) eta_last[ulane] = l_eta_last + eta_zero;               // P:181
 }
 
-template <int NLEV, int TPW, int MINW, bool NT, bool COEF_LDS = false, bool RELOAD_T = false>
+template <int NLEV, int TPW, int MINW, bool NT, bool COEF_LDS = false, bool RELOAD_T = false, bool BATCH = false>
 static hipError_t launch_np8(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = NLEV / TPW * 64;
   const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
   if (k.qn0 >= 0)
-    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT, COEF_LDS, RELOAD_T>), dim3(grid), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT, COEF_LDS, RELOAD_T, BATCH>), dim3(grid), dim3(THREADS), 0, stream, k);
   else  // dry branch (P:128-139)
-    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false, NT, COEF_LDS, RELOAD_T>), dim3(grid), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false, NT, COEF_LDS, RELOAD_T, BATCH>), dim3(grid), dim3(THREADS), 0, stream, k);
   return hipGetLastError();
 }
 
 // (non-const on purpose, see caar_np4.hip)
 KernelVariant kNp8Nlev72[] = {
-    {"caar_np8_kernel<72, 9, 1, true, true, true, false>", "8 waves x 9 levels, nt, Dvv slices re-read from LDS", launch_np8<72, 9, 1, true, true, false>},
-    {"caar_np8_kernel<72, 9, 1, true, true, true, true>", "8 waves x 9 levels, nt, Dvv slices from LDS, T re-read in the last phase", launch_np8<72, 9, 1, true, true, true>},
-    {"caar_np8_kernel<72, 9, 1, true, true, false, false>", "8 waves x 9 levels, nt, Dvv slices in registers", launch_np8<72, 9, 1, true, false, false>},
-    {"caar_np8_kernel<72, 9, 1, true, false, true, false>", "8 waves x 9 levels, default cache policy", launch_np8<72, 9, 1, false, true, false>},
-    {"caar_np8_kernel<72, 18, 1, true, true, false, false>", "4 waves x 18 levels (one wave per SIMD, 512 registers), nt", launch_np8<72, 18, 1, true, false, false>},
+    {"caar_np8_kernel<72, 9, 1, true, true, true, false, false>", "8 waves x 9 levels, nt, Dvv slices re-read from LDS", launch_np8<72, 9, 1, true, true, false, false>},
+    {"caar_np8_kernel<72, 9, 1, true, true, true, false, true>", "8 waves x 9 levels, nt, Dvv slices from LDS, operators batched per level", launch_np8<72, 9, 1, true, true, false, true>},
+    {"caar_np8_kernel<72, 9, 1, true, true, true, true, true>", "8 waves x 9 levels, nt, Dvv slices from LDS, T re-read, operators batched", launch_np8<72, 9, 1, true, true, true, true>},
+    {"caar_np8_kernel<72, 9, 1, true, true, true, true, false>", "8 waves x 9 levels, nt, Dvv slices from LDS, T re-read in the last phase", launch_np8<72, 9, 1, true, true, true, false>},
+    {"caar_np8_kernel<72, 9, 1, true, true, false, false, false>", "8 waves x 9 levels, nt, Dvv slices in registers", launch_np8<72, 9, 1, true, false, false, false>},
+    {"caar_np8_kernel<72, 9, 1, true, false, true, false, false>", "8 waves x 9 levels, default cache policy", launch_np8<72, 9, 1, false, true, false, false>},
+    {"caar_np8_kernel<72, 18, 1, true, true, false, false, true>", "4 waves x 18 levels (one wave per SIMD), nt, operators batched", launch_np8<72, 18, 1, true, false, false, true>},
 };
 int kNp8Nlev72Count = sizeof(kNp8Nlev72) / sizeof(kNp8Nlev72[0]);
 

@@ -46,6 +46,26 @@ __device__ __forceinline__ double d_db_tile(const Ctx& c) {
   for (int k = 0; k < NP; ++k) s += (COEF_LDS ? c.dvvT[c.b * NP + k] : c.cb[k]) * c.tile[c.a * NP + k];
   return s;
 }
+// The same two contractions of the field stored in tile slot j (c.tile + 64*j): the batched
+// form writes all fields of a level into their own slots first, so the LDS round trip is
+// paid once per level instead of once per operator.
+template <bool COEF_LDS>
+__device__ __forceinline__ double d_da_slot(const Ctx& c, int j) {
+  const double* t = c.tile + 64 * j;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) s += (COEF_LDS ? c.dvvT[c.a * NP + k] : c.ca[k]) * t[k * NP + c.b];
+  return s;
+}
+template <bool COEF_LDS>
+__device__ __forceinline__ double d_db_slot(const Ctx& c, int j) {
+  const double* t = c.tile + 64 * j;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) s += (COEF_LDS ? c.dvvT[c.b * NP + k] : c.cb[k]) * t[c.a * NP + k];
+  return s;
+}
+
 __device__ __forceinline__ void put_tile(const Ctx& c, int lane, double f) {
   wave_lds_fence();  // earlier reads of the tile are done
   c.tile[lane] = f;
