@@ -126,3 +126,35 @@ def test_shard_range_partitions_exactly():
             seen += list(range(a, b))
         assert seen == list(range(E))
     assert tsa.shard_range(100000, 3, 8) == (37500, 50000)
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path, lib):
+    """include/caar.h must be usable from C (the ABI is a C ABI): compile a C99 translation
+    unit against it with gcc -Wall -Werror, link it to libcaar_hip.so and run the calls that
+    need no GPU."""
+    import subprocess
+    src = tmp_path / "abi_probe.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "caar.h"
+int main(void) {
+  CaarDims d = {4, 72, 1, 3, 10};
+  CaarParams p = {0};
+  CaarArrays a = {0};
+  if (caar_abi_version() != CAAR_ABI_VERSION) return 1;
+  if (!caar_supported(4, 72) || caar_supported(3, 3)) return 2;
+  if (caar_array_len(&d, 7) != 10LL * 3 * 72 * 16 * 2) return 3;
+  if (caar_algorithmic_bytes(4, 72, 0) != 213888) return 4;
+  p.nete = 11; /* > num_elems: refused before any device is touched */
+  if (caar_launch(&d, &a, 0, &p, 0) != CAAR_EINVAL) return 5;
+  printf("%s|%s\n", caar_kernel_name(4, 72), caar_strerror(CAAR_EUNSUPPORTED));
+  return 0;
+}
+''')
+    exe = tmp_path / "abi_probe"
+    csrc = os.path.join(ROOT, "tinman_sandbox_amd", "csrc")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    str(src), "-L" + csrc, "-lcaar_hip", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib",
+                    "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert "caar_np4_kernel<72" in out and "no kernel" in out
