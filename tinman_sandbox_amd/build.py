@@ -54,7 +54,8 @@ def build_host_driver(force=False, verbose=False, np_=4, nlev=72):
     shim = os.path.join(HOST, "libhomme_caar%s.so" % suffix)
     exe = os.path.join(HOST, "caar_driver%s" % suffix)
     hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")]
-    link = ["-L" + CSRC, "-lcaar_hip", "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"]
+    # $ORIGIN-relative run paths: the tree can be moved (the GPU box mounts it elsewhere)
+    link = ["-L" + CSRC, "-lcaar_hip", "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath,/opt/rocm/lib"]
     shim_srcs = [os.path.join(HOST, "homme_caar.cpp"), os.path.join(HOST, "homme_data.cpp")]
     if force or _stale(shim, shim_srcs + hdrs + [LIB]):
         cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared"] + defs + inc + shim_srcs + link + ["-o", shim]
@@ -63,7 +64,7 @@ def build_host_driver(force=False, verbose=False, np_=4, nlev=72):
         subprocess.run(cmd, check=True)
     if force or _stale(exe, [os.path.join(HOST, "caar_driver.cpp"), shim] + hdrs):
         cmd = ["g++", "-std=c++17", "-O2"] + defs + inc + [os.path.join(HOST, "caar_driver.cpp")] + \
-              ["-L" + HOST, "-lhomme_caar%s" % suffix, "-Wl,-rpath," + HOST] + link + ["-o", exe]
+              ["-L" + HOST, "-lhomme_caar%s" % suffix, "-Wl,-rpath,$ORIGIN"] + link + ["-o", exe]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
@@ -84,7 +85,8 @@ def build_fortran_driver(force=False, verbose=False):
     srcs = [os.path.join(fdir, "caar_mod.F90"), os.path.join(fdir, "caar_f90_driver.F90")]
     if force or _stale(exe, srcs + [LIB]):
         os.makedirs(out, exist_ok=True)
-        cmd = [FLANG, "-O2", "-module-dir", out] + srcs + ["-L" + CSRC, "-lcaar_hip", "-Wl,-rpath," + CSRC,
+        cmd = [FLANG, "-O2", "-module-dir", out] + srcs + ["-L" + CSRC, "-lcaar_hip",
+                                                             "-Wl,-rpath,$ORIGIN/../../../csrc",
                                                              "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
         if verbose:
             print(" ".join(cmd))
