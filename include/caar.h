@@ -90,8 +90,8 @@ typedef struct CaarParams {
   const double *Dvv;   /* HOST pointer, np*np doubles, row-major Dvv[i][j]           */
 } CaarParams;
 
-/* 1 if a kernel is compiled for (np, nlev), else 0.  Compiled: np=4 with nlev 32, 60, 64, 72, 80,
- * 96, 128; np=8 with nlev 72. */
+/* 1 if a kernel is compiled for (np, nlev), else 0.  Compiled: np=4 with nlev 26, 30, 32, 60, 64, 72,
+ * 80, 96, 128; np=8 with nlev 72. */
 int caar_supported(int np, int nlev);
 /* CAAR_ABI_VERSION the library was built with. */
 int caar_abi_version(void);

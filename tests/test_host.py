@@ -40,9 +40,9 @@ def test_supported_variants_and_names(lib):
     assert lib.lib.caar_supported(4, 72) == 1
     assert lib.lib.caar_supported(4, 128) == 1
     assert lib.lib.caar_supported(5, 72) == 0
-    for nlev in (32, 60, 64, 80, 96):
+    for nlev in (26, 30, 32, 60, 64, 80, 96):
         assert lib.lib.caar_supported(4, nlev) == 1
-    assert lib.lib.caar_supported(4, 26) == 0 and lib.lib.caar_supported(8, 128) == 0
+    assert lib.lib.caar_supported(4, 27) == 0 and lib.lib.caar_supported(8, 128) == 0
     assert b"caar" in lib.lib.caar_kernel_name(4, 72)
     assert lib.lib.caar_kernel_name(3, 3) is None
     assert lib.lib.caar_strerror(-2).decode().startswith("no kernel")

@@ -20,7 +20,7 @@ extern KernelVariant kNp4Nlev128[];
 extern int kNp4Nlev128Count;
 extern KernelVariant kNp8Nlev72[];
 extern int kNp8Nlev72Count;
-extern KernelVariant kNp4Nlev32[], kNp4Nlev60[], kNp4Nlev64[], kNp4Nlev80[], kNp4Nlev96[];
+extern KernelVariant kNp4Nlev32[], kNp4Nlev60[], kNp4Nlev64[], kNp4Nlev80[], kNp4Nlev96[], kNp4Nlev26[], kNp4Nlev30[];
 hipError_t launch_state_norms(const double* v, const double* T, const double* dp, int np, int nlev,
                               int timelevels, int tl, int e0, int e1, double* out3_per_elem,
                               hipStream_t stream);
@@ -51,6 +51,8 @@ static Config* configs(int* n) {
       {4, 64, kNp4Nlev64, 1, 0},
       {4, 80, kNp4Nlev80, 1, 0},
       {4, 96, kNp4Nlev96, 1, 0},
+      {4, 26, kNp4Nlev26, 1, 0},
+      {4, 30, kNp4Nlev30, 1, 0},
   };
   c[0].count = kNp4Nlev72Count;
   c[1].count = kNp4Nlev128Count;

@@ -70,13 +70,15 @@ enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, 
 // next element's n0 inputs while it computes the last phase of the current one, so neither the
 // workgroup launch nor the first HBM round trip of an element is exposed (one workgroup per CU).
 template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, int PF, bool PERSIST, bool ETA_COND>
-__global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
+__global__ __launch_bounds__((NLEV + 3) / 4 / TPW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
   constexpr int PP = 16;               // GLL points per level
-  constexpr int NT = NLEV / 4;         // tiles per element
+  constexpr int NT = (NLEV + 3) / 4;   // tiles per element (the last one partly empty if NLEV % 4 != 0)
+  constexpr bool RAGGED = NLEV % 4 != 0;
   constexpr int WAVES = NT / TPW;
   constexpr int THREADS = WAVES * 64;
   constexpr int BLK = NLEV * PP;       // doubles in one scalar field block
-  static_assert(NLEV % 4 == 0 && NT % TPW == 0, "tile decomposition");
+  static_assert(NT % TPW == 0, "tile decomposition");
+  static_assert(!RAGGED || !PERSIST, "ragged level counts: non-persistent form only");
 
   __shared__ double s_dvv[16];
   __shared__ double s_geo_buf[PERSIST ? 2 : 1][G_SIZE];  // double-buffered across elements
@@ -90,6 +92,10 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
   const int pt = lane & 15;
   const int sub = lane >> 4;
   const size_t tl = (size_t)k.timelevels;
+  // RAGGED (NLEV not a multiple of 4): the rows of the last tile beyond level NLEV-1 are dead:
+  // their loads are masked and return 0, they contribute 0 to the three integrals, and they
+  // store nothing.  DPP rows are one level each, so dead rows never feed live ones.
+  auto live_row = [&](int r) { return !RAGGED || ((w * TPW + r) * 4 + sub) < NLEV; };
   // Addressing: every field pointer below is wave-uniform (element, time level and this
   // wave's first tile folded in: an SGPR pair) and is indexed by `r * 64 + ulane` with r
   // a compile-time tile number and ulane an UNSIGNED lane id, so each access is one
@@ -114,12 +120,15 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
     N0In x;
 #pragma unroll
     for (int r = 0; r < TPW; ++r) {
-      x.dp[r] = stream_load<SNT>(dp_n0 + r * 64 + ulane);
-      const dbl2 uv = stream_load<SNT>(v_n0 + r * 64 + ulane);
-      x.u[r] = uv.x;
-      x.v[r] = uv.y;
-      x.T[r] = stream_load<SNT>(T_n0 + r * 64 + ulane);
-      x.q[r] = MOIST ? stream_load<SNT>(Qdp + r * 64 + ulane) : 0.0;
+      x.dp[r] = x.u[r] = x.v[r] = x.T[r] = x.q[r] = 0.0;
+      if (live_row(r)) {
+        x.dp[r] = stream_load<SNT>(dp_n0 + r * 64 + ulane);
+        const dbl2 uv = stream_load<SNT>(v_n0 + r * 64 + ulane);
+        x.u[r] = uv.x;
+        x.v[r] = uv.y;
+        x.T[r] = stream_load<SNT>(T_n0 + r * 64 + ulane);
+        x.q[r] = MOIST ? stream_load<SNT>(Qdp + r * 64 + ulane) : 0.0;
+      }
     }
     return x;
   };
@@ -175,7 +184,8 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
     };
     auto load_tile = [&](int r) {
       const unsigned off = r * 64 + ulane;
-      TileIn x;
+      TileIn x = {};
+      if (!live_row(r)) return x;
       x.vnm1 = stream_load<SNT>(v_nm1 + off);
       x.Tnm1 = stream_load<SNT>(T_nm1 + off);
       x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
       const int t = w * TPW + r;
       divdp[r] = divergence_sphere(c, Dinv, metdet, rmetdet, rrearth, u[r] * dp[r], v[r] * dp[r]);  // P:114-121
       Tv[r] = MOIST ? T[r] * (1.0 + k.rv_over_rd_m1 * (q[r] * recip(dp[r]))) : T[r];               // P:135,150-151
+      if (RAGGED && !live_row(r)) Tv[r] = 0.0;  // dead row: dp == 0 made the line above NaN
       double in_dp, in_div;
       scan_down(dp[r], lane, sub, in_dp, ex_dp[r]);
       scan_down(divdp[r], lane, sub, in_div, ex_div[r]);
@@ -246,7 +257,8 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
         p[r] = (k.p_top + (base_dp + ex_dp[r])) + 0.5 * dp[r];  // P:84,94-96 in closed form
         suml[r] = base_div + ex_div[r];                          // P:327,339: sum of divdp above
         rp[r] = recip(p[r]);
-        const double ht = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);    // Rgas*T_v*hkl, hkl = dp/p (P:300-302)
+        double ht = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);          // Rgas*T_v*hkl, hkl = dp/p (P:300-302)
+        if (RAGGED && !live_row(r)) ht = 0.0;
         double in_ht;
         scan_up(ht, lane, sub, in_ht, ex_ht[r]);
         if (sub == 0) s_tot_ht[t * PP + pt] = in_ht;
@@ -322,6 +334,10 @@ __global__ __launch_bounds__(NLEV / 4 / TPW * 64, MINW) void caar_np4_kernel(con
       const double vtens2 = -u[r] * (fcor + vort) - gE1 - glnps2;   // P:228
       const double ttens = -vgrad_T + k.kappa * Tv[r] * om;         // P:230 (T_vadv == 0)
 
+      if (RAGGED && !live_row(r)) {
+        cur = nxt;
+        continue;
+      }
       dbl2 vo;
       vo.x = spheremp * (cur.vnm1.x + k.dt2 * vtens1);              // P:251
       vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);              // P:252
@@ -370,7 +386,7 @@ static int cu_count() {
 
 template <int NLEV, int TPW, int MINW, bool NT, int PF = 0, int PERSIST_WG_PER_CU = 0, bool ETA_COND = false>
 static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
-  constexpr int THREADS = NLEV / 4 / TPW * 64;
+  constexpr int THREADS = (NLEV + 3) / 4 / TPW * 64;
   constexpr bool PERSIST = PERSIST_WG_PER_CU > 0;
   int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
   if (PERSIST) {
@@ -417,5 +433,8 @@ KernelVariant kNp4Nlev60[] = {{"caar_np4_kernel<60, 3, 1, true, true, 1, false, 
 KernelVariant kNp4Nlev64[] = {{"caar_np4_kernel<64, 2, 1, true, true, 1, false, false>", "8 waves x 2 tiles, nt", launch_np4<64, 2, 1, true, 1>}};
 KernelVariant kNp4Nlev80[] = {{"caar_np4_kernel<80, 2, 1, true, true, 1, false, false>", "10 waves x 2 tiles, nt", launch_np4<80, 2, 1, true, 1>}};
 KernelVariant kNp4Nlev96[] = {{"caar_np4_kernel<96, 3, 1, true, true, 1, false, false>", "8 waves x 3 tiles, nt", launch_np4<96, 3, 1, true, 1>}};
+// level counts that are not a multiple of 4 (last tile partly empty)
+KernelVariant kNp4Nlev26[] = {{"caar_np4_kernel<26, 1, 1, true, true, 1, false, false>", "7 waves x 1 tile (last tile: 2 of 4 levels), nt", launch_np4<26, 1, 1, true, 1>}};
+KernelVariant kNp4Nlev30[] = {{"caar_np4_kernel<30, 2, 1, true, true, 1, false, false>", "4 waves x 2 tiles (last tile: 2 of 4 levels), nt", launch_np4<30, 2, 1, true, 1>}};
 
 }  // namespace caar
