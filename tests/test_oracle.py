@@ -145,3 +145,21 @@ def test_live_reference_init_and_norm(oracle):
     assert np.array_equal(sc["hyai"], sc_r["hyai"])
     f = arrs_o["elem_state_v"][0, 1]
     assert oracle.compute_norm(f) == R.compute_norm(f)
+
+
+@needs_ref
+@pytest.mark.parametrize("levels", [(0, 1, 0), (1, 1, 0), (0, 1, 1), (2, 2, 2)])
+def test_live_reference_aliased_time_levels(oracle, levels):
+    """Coinciding time-level indices (HOMME's Runge-Kutta stages): the oracle follows the
+    reference's statement order (all n0 reads before the update loop, P:236-257), so it
+    has to stay bit-identical when n0, np1 and nm1 alias."""
+    R = po.Reference(4, 72)
+    arrs = cases.hashed_arrays(4, 72, 2, seed=140)
+    Dvv = cases.dvv_for(4)
+    sc = po.default_scalars(72)
+    sc.update(n0=levels[0], np1=levels[1], nm1=levels[2], qn0=1, dt2=0.25, eta_ave_w=0.5)
+    a, b = cases.copy_arrays(arrs), cases.copy_arrays(arrs)
+    oracle.compute_and_apply_rhs(a, Dvv, sc)
+    R.compute_and_apply_rhs(b, Dvv, sc)
+    for n in po.ARRAY_NAMES:
+        assert np.array_equal(a[n], b[n]), n

@@ -307,3 +307,29 @@ def test_other_level_counts_match_oracle(oracle, nlev):
     for n in po.ARRAY_NAMES:  # level counts that are not a multiple of 4 must not write out of range
         if n not in cases.OUTPUT_NAMES:
             assert np.array_equal(got[n], arrs[n]), n
+
+
+ALIASED = [(0, 1, 0), (1, 1, 0), (0, 1, 1), (2, 2, 2)]
+
+
+@pytest.mark.parametrize("np_,nlev", [(4, 72), (4, 128), (8, 72), (4, 30)])
+def test_aliased_time_levels_match_oracle(oracle, np_, nlev):
+    """HOMME's Runge-Kutta stages call the routine with coinciding time-level indices
+    (nm1 == n0: a forward step; n0 == np1: u(np1) = u(nm1) + dt*RHS(u(np1))).  The reference
+    reads every n0 field into temporaries before its final update loop (P:236-257), so
+    aliasing is well defined; every tuning variant has to give the same answer."""
+    lib = tsa.library().lib
+    arrs = cases.hashed_arrays(np_, nlev, 2, seed=120 + nlev + np_)
+    Dvv = cases.dvv_for(np_)
+    try:
+        for v in range(lib.caar_num_variants(np_, nlev)):
+            lib.caar_select_variant(np_, nlev, v)
+            for (n0, np1, nm1) in ALIASED:
+                sc = po.default_scalars(nlev)
+                sc.update(n0=n0, np1=np1, nm1=nm1, qn0=1, dt2=0.25, eta_ave_w=0.5)
+                want = cases.copy_arrays(arrs)
+                oracle.compute_and_apply_rhs(want, Dvv, sc)
+                _, got = run_gpu(arrs, Dvv, sc)
+                check_outputs(got, want, sc, "alias%d%d%d_v%d" % (n0, np1, nm1, v))
+    finally:
+        lib.caar_select_variant(np_, nlev, 0)
