@@ -216,6 +216,23 @@ int caar_state_norms(CaarContext *ctx, int tl, int e0, int e1, double out[3]);
  * *ms_total receives the elapsed milliseconds.  Synchronous. */
 int caar_time_runs(CaarContext *ctx, const CaarParams *params, int reps, float *ms_total);
 
+/* ---- host-mapped API: run directly on the host's arrays, no device copies ---------
+ * For a host that calls the path like the reference does — Homme::compute_and_apply_rhs(
+ * TestData&) on arrays it owns in host memory (P:15, data_structures.cpp:14-31) — the
+ * cheapest route over PCIe is not upload + kernel + download (every array, every time
+ * level, both directions) but the kernel itself reading and writing host memory: each
+ * input byte crosses the link once, each output byte once, reads and writes overlap on
+ * the full-duplex link, and no HBM is allocated.
+ * caar_map_host page-locks the 16 host arrays (num_elems elements each, C++ layout) for
+ * HIP device `device`; the host keeps ownership and may read/write them between calls.
+ * caar_run_mapped performs one compute_and_apply_rhs on them and returns when the results
+ * are visible to the host (synchronous, like the reference's function).
+ * caar_unmap_host releases the page locks; call it before freeing the arrays. */
+typedef struct CaarHostMapping CaarHostMapping;
+int caar_map_host(CaarHostMapping **map, const CaarDims *dims, const CaarArrays *host, int device);
+int caar_run_mapped(CaarHostMapping *map, const CaarParams *params);
+int caar_unmap_host(CaarHostMapping *map);
+
 #ifdef __cplusplus
 }
 #endif

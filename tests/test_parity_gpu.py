@@ -333,3 +333,36 @@ def test_aliased_time_levels_match_oracle(oracle, np_, nlev):
                 check_outputs(got, want, sc, "alias%d%d%d_v%d" % (n0, np1, nm1, v))
     finally:
         lib.caar_select_variant(np_, nlev, 0)
+
+
+def test_host_mapped_arrays_roundtrip(oracle):
+    """caar_map_host / caar_run_mapped / caar_unmap_host: the kernel runs directly on
+    page-locked host arrays (what Homme::compute_and_apply_rhs(TestData&) uses for arrays
+    the host owns); the host sees the results when the call returns and may change the
+    arrays between calls."""
+    import ctypes as C
+    from tinman_sandbox_amd import caar as m
+    L = tsa.library()
+    arrs, Dvv, sc = cases.make_case("np4_nlev72_hashed")
+    host = cases.copy_arrays(arrs)
+    ne = host["elem_fcor"].shape[0]
+    dims = m._CaarDims(4, 72, 1, 3, ne)
+    ptrs = m._CaarArrays(*[host[n].ctypes.data_as(m._dp) for n in m.ARRAY_NAMES])
+    mp = C.c_void_p()
+    L.check(L.lib.caar_map_host(C.byref(mp), C.byref(dims), C.byref(ptrs), 0), "map_host")
+    try:
+        want = cases.copy_arrays(arrs)
+        s = dict(sc)
+        for step in range(3):
+            oracle.compute_and_apply_rhs(want, Dvv, s)
+            prm = tsa.TestData.from_numpy(arrs, Dvv, s, device="cpu").params()
+            L.check(L.lib.caar_run_mapped(mp, C.byref(prm)), "run_mapped")
+            check_outputs(host, want, s, "mapped%d" % step)
+            # the host edits its arrays in place between calls; the next call must see the edit
+            host["elem_state_T"][:, s["n0"]] += 1.0
+            want["elem_state_T"][:, s["n0"]] += 1.0
+        for n in po.ARRAY_NAMES:
+            if n not in cases.OUTPUT_NAMES and n != "elem_state_T":
+                assert np.array_equal(host[n], arrs[n]), n
+    finally:
+        L.check(L.lib.caar_unmap_host(mp), "unmap_host")

@@ -507,4 +507,84 @@ int caar_time_runs(CaarContext* c, const CaarParams* p, int reps, float* ms_tota
   return rc;
 }
 
+// ------------------------------------------------------------------ host-mapped API
+struct CaarHostMapping {
+  CaarDims dims;
+  int device;
+  hipStream_t stream;
+  CaarArrays host;       // what was registered (for hipHostUnregister)
+  bool registered[CAAR_NUM_ARRAYS];
+  CaarArrays dev;        // the same memory as the device addresses it
+  double* dvv_dev;
+  double dvv_host[64];
+  bool dvv_valid;
+};
+
+int caar_unmap_host(CaarHostMapping* m) {
+  if (!m) return CAAR_EINVAL;
+  (void)hipSetDevice(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  int rc = CAAR_OK;
+  for (int i = 0; i < CAAR_NUM_ARRAYS; ++i)
+    if (m->registered[i]) {
+      hipError_t e = hipHostUnregister(*array_slot(&m->host, i));
+      if (e != hipSuccess && rc == CAAR_OK) rc = (int)e;
+    }
+  if (m->dvv_dev) (void)hipFree(m->dvv_dev);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+  return rc;
+}
+
+int caar_map_host(CaarHostMapping** out, const CaarDims* dims, const CaarArrays* host, int device) {
+  if (!out || !dims || !host || dims->num_elems <= 0 || dims->qsize_d < 1 || dims->timelevels < 1)
+    return CAAR_EINVAL;
+  if (!caar::find_config(dims->np, dims->nlev)) return CAAR_EUNSUPPORTED;
+  for (int i = 0; i < CAAR_NUM_ARRAYS; ++i)
+    if (!*array_slot(host, i)) return CAAR_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CAAR_ENODEVICE;
+  if (device < 0 || device >= ndev) return CAAR_EINVAL;
+  HIP_TRY(hipSetDevice(device));
+  CaarHostMapping* m = new (std::nothrow) CaarHostMapping();
+  if (!m) return CAAR_ENOMEM;
+  std::memset(m, 0, sizeof(*m));
+  m->dims = *dims;
+  m->device = device;
+  m->host = *host;
+  hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+  for (int i = 0; e == hipSuccess && i < CAAR_NUM_ARRAYS; ++i) {
+    double* h = *array_slot(host, i);
+    e = hipHostRegister(h, sizeof(double) * (size_t)caar_array_len(dims, i), hipHostRegisterMapped);
+    if (e == hipSuccess) m->registered[i] = true;
+    if (e == hipErrorHostMemoryAlreadyRegistered) {  // the host pinned it itself: use it as it is
+      (void)hipGetLastError();
+      e = hipSuccess;
+    }
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)array_slot(&m->dev, i), h, 0);
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)&m->dvv_dev, sizeof(double) * 64);
+  if (e != hipSuccess) {
+    (void)caar_unmap_host(m);
+    return e == hipErrorOutOfMemory ? CAAR_ENOMEM : (int)e;
+  }
+  *out = m;
+  return CAAR_OK;
+}
+
+int caar_run_mapped(CaarHostMapping* m, const CaarParams* p) {
+  if (!m || !p || !p->Dvv) return CAAR_EINVAL;
+  HIP_TRY(hipSetDevice(m->device));
+  const size_t n = sizeof(double) * m->dims.np * m->dims.np;
+  if (!m->dvv_valid || std::memcmp(m->dvv_host, p->Dvv, n) != 0) {
+    std::memcpy(m->dvv_host, p->Dvv, n);
+    HIP_TRY(hipMemcpyAsync(m->dvv_dev, m->dvv_host, n, hipMemcpyHostToDevice, m->stream));
+    m->dvv_valid = true;
+  }
+  int rc = caar_launch(&m->dims, &m->dev, m->dvv_dev, p, m->stream);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return CAAR_OK;
+}
+
 }  // extern "C"

@@ -56,6 +56,8 @@ void usage() {
             << "|  --tinman-update-levels=val: rotate time levels between runs (default=no)|\n"
             << "|  --tinman-device=N         : first HIP device to run on (default=0)      |\n"
             << "|  --tinman-num-devices=N    : shard the elements over N GPUs (default=1)  |\n"
+            << "|  --tinman-host-arrays=val  : arrays stay in host memory, as in the       |\n"
+            << "|                              reference's loop (default=no: GPU-resident) |\n"
             << "|  --tinman-help             : prints this message                         |\n"
             << "+--------------------------------------------------------------------------+\n";
 }
@@ -64,7 +66,7 @@ void usage() {
 
 int main(int argc, char** argv) {
   using namespace Homme;
-  bool dump_res = false, update_levels = false;
+  bool dump_res = false, update_levels = false, host_arrays = false;
   int num_exec = 1, device = 0, num_devices = 1;
 
   for (int i = 1; i < argc; ++i) {
@@ -89,6 +91,8 @@ int main(int argc, char** argv) {
       num_devices = std::atoi(val);
     } else if (starts_with(a, "--tinman-dump-res=")) {
       if (!parse_yes_no(a, val, &dump_res)) return 1;
+    } else if (starts_with(a, "--tinman-host-arrays=")) {
+      if (!parse_yes_no(a, val, &host_arrays)) return 1;
     } else if (starts_with(a, "--tinman-update-levels=")) {
       if (!parse_yes_no(a, val, &update_levels)) return 1;
     } else if (starts_with(a, "--tinman-help")) {
@@ -109,6 +113,32 @@ int main(int argc, char** argv) {
   std::cout << " --- Initializing data...\n";
   data.init_data();
   print_results_2norm(data);
+
+  if (host_arrays) {
+    // The reference's own loop (main.cpp:113-121): the arrays stay where TestData allocated
+    // them and every call goes through Homme::compute_and_apply_rhs(TestData&), i.e. over PCIe.
+    std::cout << " --- Performing computations on host-resident arrays... (" << num_exec
+              << " executions of the main loop on " << num_elems << " elements)\n";
+    double first = 0, rest = 0;
+    for (int i = 0; i < num_exec; ++i) {
+      const auto h0 = std::chrono::steady_clock::now();
+      compute_and_apply_rhs(data);
+      const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count();
+      (i == 0 ? first : rest) += s;
+      if (update_levels && i + 1 < num_exec) data.update_time_levels();
+    }
+    std::cout << "   ---> compute_and_apply_rhs execution total time: " << first + rest << " s  (first call, which "
+              << "page-locks the arrays: " << first << " s";
+    if (num_exec > 1)
+      std::cout << "; then " << rest / (num_exec - 1) << " s per call = " << double(num_elems) * (num_exec - 1) / rest
+                << " element-updates/s including PCIe";
+    std::cout << "; kernel " << caar_kernel_name(np, nlev) << ")\n";
+    print_results_2norm(data);
+    if (dump_res) dump_results_to_file(data);
+    std::cout << " --- Cleaning up data...\n";
+    data.cleanup_data();
+    return 0;
+  }
 
   // Element sharding: contiguous slabs, one DeviceSession (context + stream)
   // and one host thread per GPU, no exchange between them.
