@@ -180,3 +180,36 @@ def test_four_time_levels(oracle):
         assert cases.scaled_err(got[n], want[n]) <= 1e-12, n
     for t in (1, 2, 3):
         assert np.array_equal(got["elem_state_T"][:, t], arrs["elem_state_T"][:, t])
+
+
+@pytest.mark.parametrize("np_,nlev,E", [(4, 72, 100000), (4, 128, 100000), (8, 72, 40000)])
+def test_whole_job_on_one_gpu_beyond_4gib_offsets(oracle, np_, nlev, E):
+    """BASELINE configs[2]/[3]'s global element count on ONE GPU (18.6 / 33 GB resident, NP=8:
+    30 GB): single arrays exceed 4 GiB, so element offsets must be 64-bit everywhere.  Elements
+    on both sides of the 4 GiB mark of state_v and the last one are checked against the oracle
+    run on copies of exactly those elements' inputs."""
+    data = tsa.TestData().init_data(E, np_, nlev, device="cuda")
+    data.control.qn0, data.control.dt2 = 0, 0.5
+    per_elem_v = data.arrays["elem_state_v"][0].numel() * 8
+    mark = (1 << 32) // per_elem_v
+    assert mark + 1 < E
+    picks = [0, mark - 1, mark, mark + 1, E // 2, E - 1]
+    sub = {n: data.arrays[n][picks].cpu().numpy().copy() for n in tsa.ARRAY_NAMES}
+    tsa.compute_and_apply_rhs(data)
+    torch.cuda.synchronize()
+    sc = po.default_scalars(nlev)
+    sc.update(qn0=0, dt2=0.5)
+    oracle.compute_and_apply_rhs(sub, data.deriv.Dvv, sc)
+    for n in tsa.caar.MUTATED:
+        got = data.arrays[n][picks].cpu().numpy()
+        assert cases.scaled_err(got, sub[n]) <= 1e-12, n
+    # every element was updated: no np1 value is left at its initial closed form
+    T1 = data.arrays["elem_state_T"][:, 1]
+    assert bool(torch.isfinite(T1).all())
+    # the on-device print_results_2norm over the whole range, against plain sums of squares
+    nv, nT, ndp = tsa.state_norms(data)
+    for got_norm, name in ((nv, "elem_state_v"), (nT, "elem_state_T"), (ndp, "elem_state_dp3d")):
+        x = data.arrays[name][:, 1]
+        assert abs(got_norm - float(torch.sqrt((x * x).sum()))) <= 1e-12 * got_norm, name
+    del data
+    torch.cuda.empty_cache()
