@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAAR_ABI_VERSION 1
+#define CAAR_ABI_VERSION 2
 
 enum {
   CAAR_OK = 0,
@@ -88,6 +88,20 @@ typedef struct CaarParams {
   double ps0;          /* HVCoord::ps0                                               */
   double hyai0;        /* HVCoord::hyai[0], the only hyai entry the path reads (P:84) */
   const double *Dvv;   /* HOST pointer, np*np doubles, row-major Dvv[i][j]           */
+  /* Vertical coordinate (Control::rsplit, level_vectorized_ppscan/Control.hpp:48-49).
+   * rsplit > 0: vertically Lagrangian — eta_dot_dpdn, T_vadv, v_vadv are zero; this is the
+   * only branch the reference's built variants contain (P:22-28) and what every golden
+   * vector covers.  rsplit == 0: Eulerian — the interface mass flux and the vertical
+   * advection of T and v are computed (fortran/routine_extracted.F90:224-262,515-517;
+   * preq_vertadv, level_vectorized_ppscan/CaarFunctor.hpp:505-547); the reference states
+   * that branch only in files it does not build, so its parity is UNPINNED.
+   * Must be set: a zero-initialised struct asks for rsplit == 0 and is refused
+   * (CAAR_EINVAL) unless the hybi pointer the call needs is given.  NP=4 and NP=8. */
+  int rsplit;
+  const double *hybi;     /* HOST pointer, nlev+1 interface coefficients (hybvcoord_mod.F90:19);
+                           * read when rsplit == 0 by caar_run / caar_run_mapped             */
+  const double *hybi_dev; /* DEVICE pointer to the same values; read when rsplit == 0 by the
+                           * stateless caar_launch (as dvv_dev: the caller uploads it once)  */
 } CaarParams;
 
 /* 1 if a kernel is compiled for (np, nlev), else 0.  Compiled: np=4 with nlev 26, 30, 32, 60, 64, 72,

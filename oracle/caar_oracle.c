@@ -149,6 +149,57 @@ void oracle_preq_omega_ps(int np, int nlev, const double *p,
   }
 }
 
+/* rsplit == 0 (Eulerian vertical coordinate): the vertical mass flux at the interfaces and the
+ * vertical advection of T and v.  PARITY UNPINNED: the reference states this branch only in
+ * files it never builds — X = compute_and_apply_rhs_test/fortran/routine_extracted.F90:224-262
+ * (eta_dot_dpdn) and cxx/level_vectorized_ppscan/CaarFunctor.hpp:505-547 (preq_vertadv, "UNTESTED",
+ * "Not currently used"; HOMME's prim_si_mod::preq_vertadv, eq. CCM2 (3.b.1)) — and holds no
+ * output for it.  eta_dot: [nlev+1][np][np]; v, v_vadv: [nlev][np][np][2]. */
+static void oracle_eulerian_vertical(int np, int nlev, const double *divdp, const double *hybi,
+                                     const double *dp, const double *T, const double *v,
+                                     double *eta_dot, double *rdp, double *T_vadv, double *v_vadv) {
+  const int npp = np * np;
+  for (int q = 0; q < npp; ++q) {
+    double sdot_sum = 0.0;                                /* X:221 */
+    for (int k = 0; k < nlev; ++k) {
+      sdot_sum = sdot_sum + divdp[k * npp + q];           /* X:237 */
+      eta_dot[(k + 1) * npp + q] = sdot_sum;              /* X:238 */
+    }
+    for (int k = 0; k < nlev - 1; ++k)                    /* X:249-251 */
+      eta_dot[(k + 1) * npp + q] = hybi[k + 1] * sdot_sum - eta_dot[(k + 1) * npp + q];
+    eta_dot[q] = 0.0;                                     /* X:253 */
+    eta_dot[nlev * npp + q] = 0.0;                        /* X:254 */
+  }
+  for (int o = 0; o < nlev * npp; ++o) rdp[o] = 1.0 / dp[o]; /* X:118 */
+  /* preq_vertadv, CaarFunctor.hpp:505-547 */
+  for (int k = 0; k < nlev; ++k) {
+    for (int q = 0; q < npp; ++q) {
+      const int o = k * npp + q;
+      double tv = 0.0, vv0 = 0.0, vv1 = 0.0;
+      if (k == 0) {                                       /* CaarFunctor.hpp:513-522 */
+        const double facp = 0.5 * rdp[o] * eta_dot[o + npp];
+        tv = facp * (T[o + npp] - T[o]);
+        vv0 = facp * (v[2 * (o + npp)] - v[2 * o]);
+        vv1 = facp * (v[2 * (o + npp) + 1] - v[2 * o + 1]);
+      } else if (k < nlev - 1) {                          /* CaarFunctor.hpp:524-537 */
+        const double facp = 0.5 * rdp[o] * eta_dot[o + npp];
+        const double facm = 0.5 * rdp[o] * eta_dot[o];
+        tv = facp * (T[o + npp] - T[o]) + facm * (T[o] - T[o - npp]);
+        vv0 = facp * (v[2 * (o + npp)] - v[2 * o]) + facm * (v[2 * o] - v[2 * (o - npp)]);
+        vv1 = facp * (v[2 * (o + npp) + 1] - v[2 * o + 1]) + facm * (v[2 * o + 1] - v[2 * (o - npp) + 1]);
+      } else {                                            /* CaarFunctor.hpp:538-546 */
+        const double facm = 0.5 * rdp[o] * eta_dot[o];
+        tv = facm * (T[o] - T[o - npp]);
+        vv0 = facm * (v[2 * o] - v[2 * (o - npp)]);
+        vv1 = facm * (v[2 * o + 1] - v[2 * (o - npp) + 1]);
+      }
+      T_vadv[o] = tv;
+      v_vadv[2 * o] = vv0;
+      v_vadv[2 * o + 1] = vv1;
+    }
+  }
+}
+
 /* P:15-278. */
 int oracle_compute_and_apply_rhs(const oracle_arrays *a, const oracle_params *c) {
   const int np = c->np, nlev = c->nlev, tl = c->timelevels, qd = c->qsize_d;
@@ -157,7 +208,9 @@ int oracle_compute_and_apply_rhs(const oracle_arrays *a, const oracle_params *c)
   if (np > 8) return -2;
 
   /* element-private temporaries (P:18-35): 13 field blocks + per-level scratch */
-  double *buf = (double *)calloc(blk * 13 + (size_t)npp * 4, sizeof(double));
+  const int eulerian = c->rsplit == 0; /* routine_extracted.F90:227: "if (rsplit>0) ... else" */
+  if (eulerian && !c->hybi) return -3;
+  double *buf = (double *)calloc(blk * 18 + (size_t)npp * 5, sizeof(double));
   if (!buf) return -1;
   double *T_v = buf;
   double *divdp = T_v + blk;
@@ -173,6 +226,11 @@ int oracle_compute_and_apply_rhs(const oracle_arrays *a, const oracle_params *c)
   double *Ephi = vt2 + blk; /* [np][np] */
   double *vgrad_T = Ephi + npp;
   double *vtemp = vgrad_T + npp; /* [np][np][2] */
+  /* rsplit == 0 only (zero otherwise, routine_extracted.F90:229-231) */
+  double *eta_dot = vtemp + 2 * npp; /* [nlev+1][np][np] */
+  double *T_vadv = eta_dot + blk + npp;
+  double *v_vadv = T_vadv + blk; /* [nlev][np][np][2] */
+  double *rdp = v_vadv + 2 * blk;
 
   for (int ie = c->nets; ie < c->nete; ++ie) {
     const double *Dinv = a->elem_Dinv + (size_t)ie * npp * 4;
@@ -228,14 +286,16 @@ int oracle_compute_and_apply_rhs(const oracle_arrays *a, const oracle_params *c)
     oracle_preq_hydrostatic(np, nlev, phis, T_v, p, dp_n0, c->Rgas, phi); /* P:161 */
     oracle_preq_omega_ps(np, nlev, p, vgrad_p, divdp, omega_p_tmp);       /* P:162 */
 
-    /* S6 accumulators (P:164-183); eta_dot_dpdn_tmp == 0 (vertically Lagrangian) */
+    if (eulerian) oracle_eulerian_vertical(np, nlev, divdp, c->hybi, dp_n0, T_n0, v_n0, eta_dot, rdp, T_vadv, v_vadv);
+
+    /* S6 accumulators (P:164-183); eta_dot_dpdn_tmp == 0 when vertically Lagrangian */
     double *omega_p = a->elem_derived_omega_p + (size_t)ie * blk;
     double *eta = a->elem_derived_eta_dot_dpdn + (size_t)ie * (blk + npp);
     for (size_t o = 0; o < blk; ++o) {
-      eta[o] += c->eta_ave_w * 0.0;               /* P:172 */
-      omega_p[o] += c->eta_ave_w * omega_p_tmp[o]; /* P:173 */
+      eta[o] += c->eta_ave_w * (eulerian ? eta_dot[o] : 0.0); /* P:172, X:271-272 */
+      omega_p[o] += c->eta_ave_w * omega_p_tmp[o];             /* P:173 */
     }
-    for (int q = 0; q < npp; ++q) eta[blk + q] += c->eta_ave_w * 0.0; /* P:181 */
+    for (int q = 0; q < npp; ++q) eta[blk + q] += c->eta_ave_w * (eulerian ? eta_dot[blk + q] : 0.0); /* P:181, X:276-277 */
 
     /* S7 tendencies (P:185-233) */
     const double *pecnd = a->elem_derived_pecnd + (size_t)ie * blk;
@@ -258,10 +318,11 @@ int oracle_compute_and_apply_rhs(const oracle_arrays *a, const oracle_params *c)
         double glnps1 = c->Rgas * gpterm * grad_p[2 * o];       /* P:221 */
         double glnps2 = c->Rgas * gpterm * grad_p[2 * o + 1];   /* P:222 */
         double v1 = v_n0[2 * o], v2 = v_n0[2 * o + 1];
-        /* v_vadv == T_vadv == 0 (P:27-28), kept in the expression as in P:227-231 */
-        vt1[o] = -0.0 + v2 * (fcor[q] + vort[o]) - vtemp[2 * q] - glnps1;     /* P:227 */
-        vt2[o] = -0.0 - v1 * (fcor[q] + vort[o]) - vtemp[2 * q + 1] - glnps2; /* P:228 */
-        ttens[o] = 0.0 - vgrad_T[q] + c->kappa * T_v[o] * omega_p_tmp[o];      /* P:230-231 */
+        /* v_vadv == T_vadv == 0 (P:27-28) unless rsplit == 0, kept in the expression as in
+         * P:227-231 / X:326-338 */
+        vt1[o] = -v_vadv[2 * o] + v2 * (fcor[q] + vort[o]) - vtemp[2 * q] - glnps1;         /* P:227 */
+        vt2[o] = -v_vadv[2 * o + 1] - v1 * (fcor[q] + vort[o]) - vtemp[2 * q + 1] - glnps2; /* P:228 */
+        ttens[o] = -T_vadv[o] - vgrad_T[q] + c->kappa * T_v[o] * omega_p_tmp[o];             /* P:230-231 */
       }
     }
 
@@ -278,7 +339,10 @@ int oracle_compute_and_apply_rhs(const oracle_arrays *a, const oracle_params *c)
         v_np1[2 * o] = spheremp[q] * (v_nm1[2 * o] + c->dt2 * vt1[o]);         /* P:251 */
         v_np1[2 * o + 1] = spheremp[q] * (v_nm1[2 * o + 1] + c->dt2 * vt2[o]); /* P:252 */
         T_np1[o] = spheremp[q] * (T_nm1[o] + c->dt2 * ttens[o]);               /* P:253 */
-        dp_np1[o] = spheremp[q] * (dp_nm1[o] - c->dt2 * divdp[o]);             /* P:254 */
+        if (eulerian) /* X:515-517 */
+          dp_np1[o] = spheremp[q] * (dp_nm1[o] - c->dt2 * (divdp[o] + eta_dot[o + npp] - eta_dot[o]));
+        else
+          dp_np1[o] = spheremp[q] * (dp_nm1[o] - c->dt2 * divdp[o]);           /* P:254 */
       }
     }
   }

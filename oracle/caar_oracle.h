@@ -6,7 +6,9 @@
  * __graft_entry__.smoke() and by bench.py's cpu_baseline leg.  Nothing in the
  * product path (tinman_sandbox_amd/, include/) may include, link or call it.
  *
- * Parity status: PINNED.  The restatement is checked (tests/test_oracle.py)
+ * Parity status: PINNED for the vertically-Lagrangian path (rsplit > 0: everything the
+ * reference builds); "parity unpinned" for the rsplit == 0 extension (see oracle_params).
+ * The restatement is checked (tests/test_oracle.py)
  *   - against the reference's own golden vectors Ttest/v1test/v2test
  *     (compute_and_apply_rhs_test/fortran/test_mod.F90:8-882), and
  *   - against outputs of the reference's C++ (cxx/pointers_only) and Fortran
@@ -64,6 +66,14 @@ typedef struct oracle_params {
   double rrearth, eta_ave_w, Rwater_vapor, Rgas, kappa;
   double ps0, hyai0;       /* only hyai[0] enters the path (P:84) */
   const double *Dvv;
+  /* rsplit > 0: vertically Lagrangian, the only branch the reference's built variants have
+   * (P:22-28: eta_dot_dpdn, T_vadv, v_vadv = 0).  rsplit == 0: Eulerian vertical coordinate,
+   * stated in the reference only in routine_extracted.F90:224-262,515-517 and
+   * level_vectorized_ppscan/CaarFunctor.hpp:505-547, neither of which it builds or tests:
+   * PARITY UNPINNED for that branch.  hybi: nlev+1 interface coefficients (hybvcoord_mod.F90:19),
+   * read only when rsplit == 0. */
+  int rsplit;
+  const double *hybi;
 } oracle_params;
 
 /* sphere_operators.cpp:9-48 / derivative_mod_base.F90:25-65 */

@@ -70,6 +70,7 @@ class _OracleParams(C.Structure):
         ("Rgas", C.c_double), ("kappa", C.c_double),
         ("ps0", C.c_double), ("hyai0", C.c_double),
         ("Dvv", _dp),
+        ("rsplit", C.c_int), ("hybi", _dp),
     ]
 
 
@@ -123,10 +124,16 @@ class Oracle:
         qd = arrs["elem_state_Qdp"].shape[1]
         nete = ne if sc.get("nete") is None else sc["nete"]
         self._keep = np.ascontiguousarray(Dvv, dtype=np.float64)
+        rsplit = int(sc.get("rsplit", 1))
+        self._hybi = None
+        if rsplit == 0:
+            self._hybi = np.ascontiguousarray(sc["hybi"], dtype=np.float64)
+            assert self._hybi.size == nlev + 1
         return _OracleParams(np_, nlev, qd, tl, sc["nets"], nete, sc["n0"], sc["np1"], sc["nm1"],
                              sc["qn0"], sc["dt2"], sc["rrearth"], sc["eta_ave_w"],
                              sc["Rwater_vapor"], sc["Rgas"], sc["kappa"], sc["ps0"],
-                             float(sc["hyai"][0]), _ptr(self._keep))
+                             float(sc["hyai"][0]), _ptr(self._keep), rsplit,
+                             _ptr(self._hybi) if rsplit == 0 else None)
 
     def compute_and_apply_rhs(self, arrs, Dvv, sc):
         a, p = self._arrays(arrs), self._params(arrs, Dvv, sc)

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(m.CaarLibrary.SYMBOLS)
     for s in declared:
         assert hasattr(lib.lib, s), s
-    assert lib.lib.caar_abi_version() == 1
+    assert lib.lib.caar_abi_version() == 2
 
 
 def test_supported_variants_and_names(lib):

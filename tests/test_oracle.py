@@ -163,3 +163,68 @@ def test_live_reference_aliased_time_levels(oracle, levels):
     R.compute_and_apply_rhs(b, Dvv, sc)
     for n in po.ARRAY_NAMES:
         assert np.array_equal(a[n], b[n]), n
+
+
+def eulerian_case(np_=4, nlev=72, ne=2, seed=150):
+    arrs = cases.hashed_arrays(np_, nlev, ne, seed=seed)
+    Dvv = cases.dvv_for(np_)
+    sc = po.default_scalars(nlev)
+    eta = np.arange(nlev + 1) / nlev
+    sc.update(qn0=1, dt2=0.25, eta_ave_w=0.5, rsplit=0, hybi=eta ** 2)   # B(eta): 0 at the top, 1 at the surface
+    return arrs, Dvv, sc
+
+
+def test_eulerian_branch_against_numpy_restatement(oracle):
+    """rsplit == 0 (PARITY UNPINNED: the reference neither builds nor tests this branch, see
+    oracle/caar_oracle.h).  What can be checked: the C restatement against an independent
+    numpy evaluation of routine_extracted.F90:224-262,515-517 and CaarFunctor.hpp:505-547,
+    fed with divdp recovered from the (pinned) vertically-Lagrangian run of the same inputs."""
+    arrs, Dvv, sc = eulerian_case()
+    lag, eul = cases.copy_arrays(arrs), cases.copy_arrays(arrs)
+    oracle.compute_and_apply_rhs(lag, Dvv, dict(sc, rsplit=1))
+    oracle.compute_and_apply_rhs(eul, Dvv, sc)
+    n0, np1, nm1, dt2, w = sc["n0"], sc["np1"], sc["nm1"], sc["dt2"], sc["eta_ave_w"]
+    sph = arrs["elem_spheremp"][:, None]
+    dp_nm1 = arrs["elem_state_dp3d"][:, nm1]
+    divdp = (dp_nm1 - lag["elem_state_dp3d"][:, np1] / sph) / dt2            # P:254 inverted
+    S = divdp.sum(axis=1, keepdims=True)
+    eta_dot = np.zeros_like(arrs["elem_derived_eta_dot_dpdn"])
+    eta_dot[:, 1:-1] = sc["hybi"][1:-1, None, None] * S - np.cumsum(divdp, axis=1)[:, :-1]
+    scale = np.abs(S).max()
+    got_eta = (eul["elem_derived_eta_dot_dpdn"] - arrs["elem_derived_eta_dot_dpdn"]) / w
+    assert np.abs(got_eta - eta_dot).max() <= 1e-9 * scale
+    assert np.array_equal(lag["elem_derived_eta_dot_dpdn"], arrs["elem_derived_eta_dot_dpdn"] + 0.0)
+    # dp3d: X:515-517
+    want_dp = sph * (dp_nm1 - dt2 * (divdp + eta_dot[:, 1:] - eta_dot[:, :-1]))
+    assert np.abs(eul["elem_state_dp3d"][:, np1] - want_dp).max() <= 1e-9 * np.abs(want_dp).max()
+    # vertical advection of T and v (CaarFunctor.hpp:505-547) through the np1 difference
+    rdp = 1.0 / arrs["elem_state_dp3d"][:, n0]
+
+    def vadv(f, ed, r):  # f: [ne][nlev][np][np](...) ; ed broadcastable
+        d = np.zeros_like(f)
+        up = 0.5 * r[:, :-1] * ed[:, 1:-1] * (f[:, 1:] - f[:, :-1])
+        d[:, :-1] += up                                                       # facp term of level k
+        d[:, 1:] += 0.5 * r[:, 1:] * ed[:, 1:-1] * (f[:, 1:] - f[:, :-1])     # facm term of level k+1
+        return d
+    T = arrs["elem_state_T"][:, n0]
+    want_T = lag["elem_state_T"][:, np1] - sph * dt2 * vadv(T, eta_dot, rdp)
+    assert np.abs(eul["elem_state_T"][:, np1] - want_T).max() <= 1e-9 * np.abs(want_T).max()
+    v = arrs["elem_state_v"][:, n0]
+    want_v = lag["elem_state_v"][:, np1] - (sph * dt2)[..., None] * vadv(v, eta_dot[..., None], rdp[..., None])
+    assert np.abs(eul["elem_state_v"][:, np1] - want_v).max() <= 1e-9 * np.abs(want_v).max()
+    # everything the vertical terms do not enter is bit-identical to the Lagrangian run
+    for n in ("elem_derived_phi", "elem_derived_omega_p", "elem_derived_vn0"):
+        assert np.array_equal(eul[n], lag[n]), n
+
+
+def test_eulerian_branch_conserves_column_mass(oracle):
+    """The interface fluxes telescope (eta_dot = 0 at the top and at the surface, X:253-254):
+    the column sum of dp3d(np1)/spheremp is the one of the vertically-Lagrangian update."""
+    arrs, Dvv, sc = eulerian_case(seed=151)
+    lag, eul = cases.copy_arrays(arrs), cases.copy_arrays(arrs)
+    oracle.compute_and_apply_rhs(lag, Dvv, dict(sc, rsplit=1))
+    oracle.compute_and_apply_rhs(eul, Dvv, sc)
+    a = eul["elem_state_dp3d"][:, sc["np1"]].sum(axis=1)
+    b = lag["elem_state_dp3d"][:, sc["np1"]].sum(axis=1)
+    assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max()
+    assert not np.array_equal(eul["elem_state_dp3d"], lag["elem_state_dp3d"])

@@ -366,3 +366,50 @@ def test_host_mapped_arrays_roundtrip(oracle):
                 assert np.array_equal(host[n], arrs[n]), n
     finally:
         L.check(L.lib.caar_unmap_host(mp), "unmap_host")
+
+
+def eulerian_scalars(nlev, **kw):
+    sc = po.default_scalars(nlev)
+    eta = np.arange(nlev + 1) / nlev
+    sc.update(qn0=1, dt2=0.25, eta_ave_w=0.5, rsplit=0, hybi=eta ** 2)
+    sc.update(kw)
+    return sc
+
+
+@pytest.mark.parametrize("np_,nlev", [(4, 72), (4, 128), (8, 72), (4, 26), (4, 30), (4, 64)])
+def test_eulerian_vertical_coordinate_matches_oracle(oracle, np_, nlev):
+    """rsplit == 0: interface mass flux eta_dot_dpdn, vertical advection of T and v, the flux
+    divergence in the dp3d update (routine_extracted.F90:224-262,515-517, CaarFunctor.hpp:505-547).
+    PARITY UNPINNED: the reference never builds this branch and holds no output for it; the
+    oracle's restatement is checked against an independent numpy evaluation in
+    tests/test_oracle.py.  Every tuning variant, moist and dry, time-level permutations."""
+    lib = tsa.library().lib
+    arrs = cases.hashed_arrays(np_, nlev, 3, seed=160 + nlev + np_)
+    Dvv = cases.dvv_for(np_)
+    try:
+        for v in range(lib.caar_num_variants(np_, nlev)):
+            lib.caar_select_variant(np_, nlev, v)
+            for extra in (dict(), dict(qn0=-1, n0=2, np1=0, nm1=1), dict(n0=1, np1=1, nm1=0, nets=1, nete=2)):
+                sc = eulerian_scalars(nlev, **extra)
+                want = cases.copy_arrays(arrs)
+                oracle.compute_and_apply_rhs(want, Dvv, sc)
+                _, got = run_gpu(arrs, Dvv, sc)
+                check_outputs(got, want, sc, "eulerian_v%d_%s" % (v, sorted(extra)))
+                for n in po.ARRAY_NAMES:
+                    if n not in cases.OUTPUT_NAMES:
+                        assert np.array_equal(got[n], arrs[n]), n
+                    else:
+                        assert np.array_equal(got[n][:sc["nets"]], arrs[n][:sc["nets"]]), n
+    finally:
+        lib.caar_select_variant(np_, nlev, 0)
+
+
+def test_eulerian_needs_hybi():
+    arrs, Dvv, sc = cases.make_case("np4_nlev72_closed")
+    data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    data.control.rsplit = 0
+    with pytest.raises(tsa.caar.CaarError):
+        tsa.compute_and_apply_rhs(data)
+    data.control.rsplit = -1
+    with pytest.raises(tsa.caar.CaarError):
+        tsa.compute_and_apply_rhs(data)

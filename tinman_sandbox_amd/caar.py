@@ -47,7 +47,8 @@ class _CaarParams(C.Structure):
     _fields_ = [("nets", C.c_int), ("nete", C.c_int), ("n0", C.c_int), ("np1", C.c_int),
                 ("nm1", C.c_int), ("qn0", C.c_int), ("dt2", C.c_double), ("rrearth", C.c_double),
                 ("eta_ave_w", C.c_double), ("Rwater_vapor", C.c_double), ("Rgas", C.c_double),
-                ("kappa", C.c_double), ("ps0", C.c_double), ("hyai0", C.c_double), ("Dvv", _dp)]
+                ("kappa", C.c_double), ("ps0", C.c_double), ("hyai0", C.c_double), ("Dvv", _dp),
+                ("rsplit", C.c_int), ("hybi", _dp), ("hybi_dev", _dp)]
 
 
 class CaarError(RuntimeError):
@@ -286,6 +287,9 @@ class Control:
         self.nets, self.nete = 0, num_elems
         self.n0, self.np1, self.nm1, self.qn0 = 0, 1, 2, 0
         self.dt2 = 1.0
+        # level_vectorized_ppscan/Control.hpp:48-49.  > 0: vertically Lagrangian (all the
+        # reference's built variants); 0: Eulerian, needs HVCoord.hybi (parity unpinned)
+        self.rsplit = 1
 
 
 class HVCoord:
@@ -294,6 +298,7 @@ class HVCoord:
     def __init__(self, nlev):
         self.ps0 = 10.0
         self.hyai = np.array([nlev + 1 - i for i in range(nlev + 1)], dtype=np.float64)
+        self.hybi = None  # nlev+1 interface coefficients (hybvcoord_mod.F90:19); read only when rsplit == 0
 
 
 NP4_DVV_VALUES = (
@@ -353,6 +358,7 @@ class TestData:
         self.hvcoord = None
         self._dvv_dev = None
         self._dvv_key = None
+        self._hybi_key = None
 
     def init_data(self, num_elems, np_=4, nlev=72, device="cuda", first_elem=0):
         """TestData::init_data, data_structures.cpp:165-172."""
@@ -380,6 +386,9 @@ class TestData:
         d.hvcoord = HVCoord(d.arrays.nlev)
         d.hvcoord.ps0 = float(scalars["ps0"])
         d.hvcoord.hyai = np.ascontiguousarray(scalars["hyai"], dtype=np.float64)
+        d.control.rsplit = int(scalars.get("rsplit", 1))
+        if scalars.get("hybi") is not None:
+            d.hvcoord.hybi = np.ascontiguousarray(scalars["hybi"], dtype=np.float64)
         d.deriv = Derivative(d.arrays.np)
         d.deriv.Dvv = np.ascontiguousarray(Dvv, dtype=np.float64)
         return d
@@ -396,12 +405,32 @@ class TestData:
             self._dvv_key = key
         return self._dvv_dev
 
-    def params(self):
+    def hybi_device(self):
+        h = np.ascontiguousarray(self.hvcoord.hybi, dtype=np.float64)
+        if h.size != self.arrays.nlev + 1:
+            raise CaarError("HVCoord.hybi must hold nlev+1 values")
+        key = (h.tobytes(), str(self.arrays.device))
+        if self._hybi_key != key:
+            self._hybi_dev = torch.from_numpy(h).to(self.arrays.device)
+            self._hybi_key = key
+        return self._hybi_dev
+
+    def params(self, device_constants=False):
+        """CaarParams for the C ABI; device_constants: also the device copy of hybi that the
+        stateless caar_launch reads when rsplit == 0."""
         c, k, h = self.control, self.constants, self.hvcoord
         self._dvv_host = np.ascontiguousarray(self.deriv.Dvv, dtype=np.float64)
+        hybi = hybi_dev = None
+        if c.rsplit == 0:
+            if h.hybi is None:
+                raise CaarError("rsplit == 0 needs HVCoord.hybi")
+            self._hybi_host = np.ascontiguousarray(h.hybi, dtype=np.float64)
+            hybi = self._hybi_host.ctypes.data_as(_dp)
+            if device_constants:
+                hybi_dev = C.cast(C.c_void_p(self.hybi_device().data_ptr()), _dp)
         return _CaarParams(c.nets, c.nete, c.n0, c.np1, c.nm1, c.qn0, c.dt2, k.rrearth, k.eta_ave_w,
                            k.Rwater_vapor, k.Rgas, k.kappa, h.ps0, float(h.hyai[0]),
-                           self._dvv_host.ctypes.data_as(_dp))
+                           self._dvv_host.ctypes.data_as(_dp), c.rsplit, hybi, hybi_dev)
 
 
 def _require_gpu(arrays):
@@ -418,7 +447,7 @@ def compute_and_apply_rhs(data, stream=None):
     _require_gpu(data.arrays)
     if stream is None:
         stream = torch.cuda.current_stream(data.arrays.device)
-    dims, ptrs, prm = data.arrays.dims(), data.arrays.pointers(), data.params()
+    dims, ptrs, prm = data.arrays.dims(), data.arrays.pointers(), data.params(device_constants=True)
     dvv = data.dvv_device()
     with torch.cuda.device(data.arrays.device):  # the launch goes to the calling thread's current HIP device
         rc = L.lib.caar_launch(C.byref(dims), C.byref(ptrs), C.c_void_p(dvv.data_ptr()),

@@ -69,6 +69,51 @@ static Config* find_config(int np, int nlev) {
 }
 }  // namespace caar
 
+namespace caar {
+// Device copies of the two small host arrays a call reads (Dvv; hybi when rsplit == 0),
+// re-uploaded only when the host values change.
+struct HostConstants {
+  double* dev;  // [64] Dvv, then [nlev + 1] hybi
+  std::vector<double>* host;
+  bool dvv_valid, hybi_valid;
+
+  hipError_t create(int nlev) {
+    host = new (std::nothrow) std::vector<double>(64 + nlev + 1, 0.0);
+    if (!host) return hipErrorOutOfMemory;
+    return hipMalloc((void**)&dev, sizeof(double) * host->size());
+  }
+  void destroy() {
+    if (dev) (void)hipFree(dev);
+    delete host;
+    dev = nullptr;
+    host = nullptr;
+  }
+  // Fills the device-side fields of *p (a copy of the caller's params) and returns dvv_dev.
+  // The staging vector lives as long as the owner, so the async copies' sources outlive the call.
+  hipError_t sync(const CaarDims& d, CaarParams* p, hipStream_t stream, const double** dvv_dev) {
+    const size_t n = (size_t)d.np * d.np;
+    if (!dvv_valid || std::memcmp(host->data(), p->Dvv, sizeof(double) * n) != 0) {
+      std::memcpy(host->data(), p->Dvv, sizeof(double) * n);
+      hipError_t e = hipMemcpyAsync(dev, host->data(), sizeof(double) * n, hipMemcpyHostToDevice, stream);
+      if (e != hipSuccess) return e;
+      dvv_valid = true;
+    }
+    if (p->rsplit == 0) {
+      const size_t m = (size_t)d.nlev + 1;
+      if (!hybi_valid || std::memcmp(host->data() + 64, p->hybi, sizeof(double) * m) != 0) {
+        std::memcpy(host->data() + 64, p->hybi, sizeof(double) * m);
+        hipError_t e = hipMemcpyAsync(dev + 64, host->data() + 64, sizeof(double) * m, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+        hybi_valid = true;
+      }
+      p->hybi_dev = dev + 64;
+    }
+    *dvv_dev = dev;
+    return hipSuccess;
+  }
+};
+}  // namespace caar
+
 static int g_xcd_chunked = 0;  // workgroup -> element mapping, see element_of_block()
 
 struct CaarContext {
@@ -76,9 +121,7 @@ struct CaarContext {
   int device;
   hipStream_t stream;
   CaarArrays dev;       // device pointers
-  double* dvv_dev;      // np*np
-  double dvv_host[64];  // last uploaded Dvv (re-upload only when it changes)
-  bool dvv_valid;
+  caar::HostConstants consts;  // Dvv and hybi on the device
   double* norms_dev;    // 3 * num_elems
   double* stage_dev;    // staging for Fortran-ordered host arrays (largest array), lazily allocated
 };
@@ -175,6 +218,7 @@ static int check_common(const CaarDims* d, const CaarParams* p) {
   if (p->n0 < 0 || p->n0 >= tl || p->np1 < 0 || p->np1 >= tl || p->nm1 < 0 || p->nm1 >= tl)
     return CAAR_EINVAL;
   if (p->qn0 < -1 || p->qn0 > 1) return CAAR_EINVAL;  // Qdp holds 2 time slots (data_structures.cpp:27)
+  if (p->rsplit < 0) return CAAR_EINVAL;
   return CAAR_OK;
 }
 
@@ -198,6 +242,7 @@ int caar_launch(const CaarDims* dims, const CaarArrays* dev, const double* dvv_d
     if ((size_t)*array_slot(dev, i) & 7) return CAAR_EINVAL;
   const caar::Config* cfg = caar::find_config(dims->np, dims->nlev);
   if (!cfg) return CAAR_EUNSUPPORTED;
+  if (p->rsplit == 0 && (!p->hybi_dev || ((size_t)p->hybi_dev & 7))) return CAAR_EINVAL;
   const int n = p->nete - p->nets;
   if (n == 0) return CAAR_OK;
 
@@ -225,6 +270,8 @@ static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const Caar
   k.pecnd = dev->elem_derived_pecnd;
   k.vn0 = dev->elem_derived_vn0;
   k.Dvv = dvv_dev;
+  k.hybi = p->rsplit == 0 ? p->hybi_dev : nullptr;
+  k.vadv = p->rsplit == 0 ? 1 : 0;
   k.nets = p->nets;
   k.nelem = p->nete - p->nets;
   k.per_xcd = g_xcd_chunked ? (k.nelem + 7) / 8 : 0;
@@ -338,7 +385,7 @@ int caar_create(CaarContext** out, const CaarDims* dims, int device) {
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; e == hipSuccess && i < CAAR_NUM_ARRAYS; ++i)
     e = hipMalloc((void**)array_slot(&c->dev, i), sizeof(double) * caar_array_len(dims, i));
-  if (e == hipSuccess) e = hipMalloc((void**)&c->dvv_dev, sizeof(double) * 64);
+  if (e == hipSuccess) e = c->consts.create(dims->nlev);
   if (e == hipSuccess) e = hipMalloc((void**)&c->norms_dev, sizeof(double) * 3 * dims->num_elems);
   if (e != hipSuccess) {
     caar_destroy(c);
@@ -354,7 +401,7 @@ void caar_destroy(CaarContext* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int i = 0; i < CAAR_NUM_ARRAYS; ++i)
     if (*array_slot(&c->dev, i)) (void)hipFree(*array_slot(&c->dev, i));
-  if (c->dvv_dev) (void)hipFree(c->dvv_dev);
+  c->consts.destroy();
   if (c->norms_dev) (void)hipFree(c->norms_dev);
   if (c->stage_dev) (void)hipFree(c->stage_dev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -446,14 +493,11 @@ int caar_download_f90(CaarContext* c, const CaarArrays* f90_host, int e0, int e1
 int caar_run(CaarContext* c, const CaarParams* p) {
   if (!c || !p || !p->Dvv) return CAAR_EINVAL;
   HIP_TRY(hipSetDevice(c->device));
-  const size_t n = sizeof(double) * c->dims.np * c->dims.np;
-  if (!c->dvv_valid || std::memcmp(c->dvv_host, p->Dvv, n) != 0) {
-    std::memcpy(c->dvv_host, p->Dvv, n);
-    // dvv_host lives in the context, so the async copy's source outlives the call
-    HIP_TRY(hipMemcpyAsync(c->dvv_dev, c->dvv_host, n, hipMemcpyHostToDevice, c->stream));
-    c->dvv_valid = true;
-  }
-  return caar_launch(&c->dims, &c->dev, c->dvv_dev, p, c->stream);
+  if (p->rsplit == 0 && !p->hybi) return CAAR_EINVAL;
+  CaarParams q = *p;
+  const double* dvv_dev = nullptr;
+  HIP_TRY(c->consts.sync(c->dims, &q, c->stream, &dvv_dev));
+  return caar_launch(&c->dims, &c->dev, dvv_dev, &q, c->stream);
 }
 
 int caar_sync(CaarContext* c) {
@@ -515,9 +559,7 @@ struct CaarHostMapping {
   CaarArrays host;       // what was registered (for hipHostUnregister)
   bool registered[CAAR_NUM_ARRAYS];
   CaarArrays dev;        // the same memory as the device addresses it
-  double* dvv_dev;
-  double dvv_host[64];
-  bool dvv_valid;
+  caar::HostConstants consts;
 };
 
 int caar_unmap_host(CaarHostMapping* m) {
@@ -530,7 +572,7 @@ int caar_unmap_host(CaarHostMapping* m) {
       hipError_t e = hipHostUnregister(*array_slot(&m->host, i));
       if (e != hipSuccess && rc == CAAR_OK) rc = (int)e;
     }
-  if (m->dvv_dev) (void)hipFree(m->dvv_dev);
+  m->consts.destroy();
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
   return rc;
@@ -563,7 +605,7 @@ int caar_map_host(CaarHostMapping** out, const CaarDims* dims, const CaarArrays*
     }
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)array_slot(&m->dev, i), h, 0);
   }
-  if (e == hipSuccess) e = hipMalloc((void**)&m->dvv_dev, sizeof(double) * 64);
+  if (e == hipSuccess) e = m->consts.create(dims->nlev);
   if (e != hipSuccess) {
     (void)caar_unmap_host(m);
     return e == hipErrorOutOfMemory ? CAAR_ENOMEM : (int)e;
@@ -575,13 +617,11 @@ int caar_map_host(CaarHostMapping** out, const CaarDims* dims, const CaarArrays*
 int caar_run_mapped(CaarHostMapping* m, const CaarParams* p) {
   if (!m || !p || !p->Dvv) return CAAR_EINVAL;
   HIP_TRY(hipSetDevice(m->device));
-  const size_t n = sizeof(double) * m->dims.np * m->dims.np;
-  if (!m->dvv_valid || std::memcmp(m->dvv_host, p->Dvv, n) != 0) {
-    std::memcpy(m->dvv_host, p->Dvv, n);
-    HIP_TRY(hipMemcpyAsync(m->dvv_dev, m->dvv_host, n, hipMemcpyHostToDevice, m->stream));
-    m->dvv_valid = true;
-  }
-  int rc = caar_launch(&m->dims, &m->dev, m->dvv_dev, p, m->stream);
+  if (p->rsplit == 0 && !p->hybi) return CAAR_EINVAL;
+  CaarParams q = *p;
+  const double* dvv_dev = nullptr;
+  HIP_TRY(m->consts.sync(m->dims, &q, m->stream, &dvv_dev));
+  int rc = caar_launch(&m->dims, &m->dev, dvv_dev, &q, m->stream);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(m->stream));
   return CAAR_OK;

@@ -26,6 +26,8 @@ struct KernelArgs {
   const double* pecnd;
   double* vn0;
   const double* Dvv;  // np*np, row-major Dvv[i][j]
+  const double* hybi; // nlev+1 interface coefficients, read only when vadv != 0
+  int vadv;           // 1: rsplit == 0, Eulerian vertical coordinate (eta_dot_dpdn, vertical advection)
   int nets;           // first element of this launch
   int nelem;          // elements in this launch
   int per_xcd;        // 0: element = nets + blockIdx.x; else XCD-chunked mapping (element_of_block)

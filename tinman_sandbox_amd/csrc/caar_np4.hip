@@ -69,7 +69,13 @@ enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, 
 // PERSIST: the workgroup walks elements blockIdx.x, blockIdx.x + gridDim.x, ... and requests the
 // next element's n0 inputs while it computes the last phase of the current one, so neither the
 // workgroup launch nor the first HBM round trip of an element is exposed (one workgroup per CU).
-template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, int PF, bool PERSIST, bool ETA_COND>
+//
+// VADV: the Eulerian vertical coordinate (rsplit == 0; routine_extracted.F90:224-262,515-517 = "X",
+// level_vectorized_ppscan/CaarFunctor.hpp:505-547 preq_vertadv): the interface mass flux eta_dot_dpdn
+// from the column total and the running sum of divdp, and the vertical advection of T and v, for
+// which T, u, v of the whole column are mirrored in LDS (the level above / below a lane's own).
+// No extra HBM traffic.  The reference never builds this branch: parity unpinned (oracle/caar_oracle.h).
+template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, int PF, bool PERSIST, bool ETA_COND, bool VADV = false>
 __global__ __launch_bounds__((NLEV + 3) / 4 / TPW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
   constexpr int PP = 16;               // GLL points per level
   constexpr int NT = (NLEV + 3) / 4;   // tiles per element (the last one partly empty if NLEV % 4 != 0)
@@ -79,12 +85,18 @@ __global__ __launch_bounds__((NLEV + 3) / 4 / TPW * 64, MINW) void caar_np4_kern
   constexpr int BLK = NLEV * PP;       // doubles in one scalar field block
   static_assert(NT % TPW == 0, "tile decomposition");
   static_assert(!RAGGED || !PERSIST, "ragged level counts: non-persistent form only");
+  static_assert(!VADV || (!PERSIST && !ETA_COND), "Eulerian branch: plain form only");
 
   __shared__ double s_dvv[16];
   __shared__ double s_geo_buf[PERSIST ? 2 : 1][G_SIZE];  // double-buffered across elements
   __shared__ double s_tot_dp[NT * PP];   // sum of dp over each tile
   __shared__ double s_tot_div[NT * PP];  // sum of divdp over each tile
   __shared__ double s_tot_ht[NT * PP];   // sum of Rgas*T_v*dp/p over each tile
+  // VADV: T, u, v at n0 of the whole column, [field][1 + level][pt] with a zero row above the
+  // top level and below the bottom one (and room for the dead rows of a ragged last tile)
+  constexpr int COL = VADV ? (NT * 4 + 2) * PP : 1;
+  __shared__ double s_col[3][COL];
+  __shared__ double s_hybi[VADV ? NT * 4 + 1 : 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -150,6 +162,16 @@ __global__ __launch_bounds__((NLEV + 3) / 4 / TPW * 64, MINW) void caar_np4_kern
   double geo_reg = 0.0;
   if (PERSIST && tid < G_SIZE) geo_reg = *geo_src((size_t)ie_s, tid);
   if (tid < 16) s_dvv[tid] = k.Dvv[tid];
+  if (VADV) {
+    for (int idx = tid; idx < NT * 4 + 1; idx += THREADS) s_hybi[idx] = idx <= NLEV ? k.hybi[idx] : 0.0;
+    if (tid < PP) {
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        s_col[f][tid] = 0.0;
+        s_col[f][(NLEV + 1) * PP + tid] = 0.0;
+      }
+    }
+  }
   RowCoef c;
   int par = 0;
   bool first = true;
@@ -240,11 +262,17 @@ __global__ __launch_bounds__((NLEV + 3) / 4 / TPW * 64, MINW) void caar_np4_kern
         s_tot_dp[t * PP + pt] = in_dp;
         s_tot_div[t * PP + pt] = in_div;
       }
+      if (VADV && live_row(r)) {
+        s_col[0][PP + t * 64 + lane] = T[r];
+        s_col[1][PP + t * 64 + lane] = u[r];
+        s_col[2][PP + t * 64 + lane] = v[r];
+      }
     }
     wg_barrier<PERSIST>();
 
     // ---- phase 2: p, running divdp sum, hydrostatic increments and their in-tile scan --
     double p[TPW], rp[TPW], suml[TPW], ex_ht[TPW];
+    double sdot_sum = 0.0;  // VADV: column total of divdp (X:237)
     {
       double base_dp = 0.0, base_div = 0.0;
       for (int t2 = 0; t2 < w * TPW; ++t2) {  // tiles above this wave's first tile (wave-uniform trip count)
@@ -264,6 +292,10 @@ __global__ __launch_bounds__((NLEV + 3) / 4 / TPW * 64, MINW) void caar_np4_kern
         if (sub == 0) s_tot_ht[t * PP + pt] = in_ht;
         base_dp += s_tot_dp[t * PP + pt];
         base_div += s_tot_div[t * PP + pt];
+      }
+      if (VADV) {
+        for (int t2 = w * TPW + TPW; t2 < NT; ++t2) base_div += s_tot_div[t2 * PP + pt];
+        sdot_sum = base_div;
       }
     }
 
@@ -330,9 +362,26 @@ __global__ __launch_bounds__((NLEV + 3) / 4 / TPW * 64, MINW) void caar_np4_kern
       const double gpterm = Tv[r] * rp[r];                          // P:219
       const double glnps1 = k.Rgas * gpterm * gp0;                  // P:221
       const double glnps2 = k.Rgas * gpterm * gp1;                  // P:222
-      const double vtens1 = v[r] * (fcor + vort) - gE0 - glnps1;    // P:227 (v_vadv == 0)
-      const double vtens2 = -u[r] * (fcor + vort) - gE1 - glnps2;   // P:228
-      const double ttens = -vgrad_T + k.kappa * Tv[r] * om;         // P:230 (T_vadv == 0)
+      double vtens1 = v[r] * (fcor + vort) - gE0 - glnps1;          // P:227 (v_vadv == 0)
+      double vtens2 = -u[r] * (fcor + vort) - gE1 - glnps2;         // P:228
+      double ttens = -vgrad_T + k.kappa * Tv[r] * om;               // P:230 (T_vadv == 0)
+      double eta_lo = 0.0, eta_hi = 0.0;  // interface mass flux above / below this level
+      if (VADV) {
+        const int lev = t * 4 + sub;
+        // X:238-254: eta_dot(k+1) = hybi(k+1)*sdot_sum - sum_{l<=k} divdp(l); 0 at the top and the surface
+        eta_lo = lev == 0 ? 0.0 : s_hybi[lev] * sdot_sum - suml[r];
+        eta_hi = lev >= NLEV - 1 ? 0.0 : s_hybi[lev + 1] * sdot_sum - (suml[r] + divdp[r]);
+        const double half_rdp = 0.5 * recip(dp[r]);                 // X:118
+        const double facp = half_rdp * eta_hi, facm = half_rdp * eta_lo;   // CaarFunctor.hpp:526-527
+        const int ci = PP + t * 64 + lane;
+        // CaarFunctor.hpp:513-546 (the zero rows of s_col stand in for the missing one-sided terms)
+        const double T_vadv = facp * (s_col[0][ci + PP] - T[r]) + facm * (T[r] - s_col[0][ci - PP]);
+        const double u_vadv = facp * (s_col[1][ci + PP] - u[r]) + facm * (u[r] - s_col[1][ci - PP]);
+        const double v_vadv = facp * (s_col[2][ci + PP] - v[r]) + facm * (v[r] - s_col[2][ci - PP]);
+        vtens1 = -u_vadv + v[r] * (fcor + vort) - gE0 - glnps1;     // X:326-328
+        vtens2 = -v_vadv - u[r] * (fcor + vort) - gE1 - glnps2;     // X:332-334
+        ttens = -T_vadv - vgrad_T + k.kappa * Tv[r] * om;           // X:338
+      }
 
       if (RAGGED && !live_row(r)) {
         cur = nxt;
@@ -343,7 +392,8 @@ __global__ __launch_bounds__((NLEV + 3) / 4 / TPW * 64, MINW) void caar_np4_kern
       vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);              // P:252
       stream_store<SNT>(v_np1 + off, vo);
       stream_store<SNT>(T_np1 + off, spheremp * (cur.Tnm1 + k.dt2 * ttens));        // P:253
-      stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * divdp[r]));   // P:254
+      if (VADV) stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * (divdp[r] + eta_hi - eta_lo)));  // X:515-517
+      else stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * divdp[r]));   // P:254
       stream_store<SNT>(phi_out + off, phi);                                        // P:294,303,309
       stream_store<SNT>(omega_p + off, cur.om + k.eta_ave_w * om);                  // P:173
       dbl2 vn;
@@ -351,7 +401,7 @@ __global__ __launch_bounds__((NLEV + 3) / 4 / TPW * 64, MINW) void caar_np4_kern
       vn.y = cur.vn0.y + k.eta_ave_w * (v[r] * dp[r]);              // P:118
       stream_store<SNT>(vn0 + off, vn);
       {
-        const double e_new = cur.eta + eta_zero;                      // P:172
+        const double e_new = cur.eta + (VADV ? k.eta_ave_w * eta_lo : eta_zero);  // P:172, X:271-272
         // ETA_COND: the update adds eta_ave_w * 0 (vertically Lagrangian), so the stored value
         // differs from the loaded one only for -0.0 or a non-finite eta_ave_w; storing only
         // then keeps the array bit-identical to the reference's and drops the write traffic.
@@ -392,6 +442,14 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
   if (PERSIST) {
     grid = cu_count() * PERSIST_WG_PER_CU;
     if (grid > num_elems) grid = num_elems;
+  }
+  if (k.vadv) {  // rsplit == 0: the plain (non-persistent, unconditional eta store) form of this shape
+    if (PERSIST) grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
+    if (k.qn0 >= 0)
+      hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true, NT, PF, false, false, true>), dim3(grid), dim3(THREADS), 0, stream, k);
+    else
+      hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false, NT, PF, false, false, true>), dim3(grid), dim3(THREADS), 0, stream, k);
+    return hipGetLastError();
   }
   if (k.qn0 >= 0)
     hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true, NT, PF, PERSIST, ETA_COND>), dim3(grid), dim3(THREADS), 0, stream, k);

@@ -28,22 +28,28 @@
 namespace caar {
 
 
-template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T, bool BATCH>
+//
+// VADV: the Eulerian vertical coordinate (rsplit == 0), see caar_np4.hip.  u and v of the
+// neighbouring levels are already in the LDS park; T of the level above a wave's first and
+// below its last level goes through a small LDS halo.
+template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T, bool BATCH, bool VADV = false>
 __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const KernelArgs k) {
   using namespace np8;
   constexpr int WAVES = NLEV / TPW;
   constexpr int THREADS = WAVES * 64;
   constexpr int BLK = NLEV * PP;
   static_assert(NLEV % TPW == 0 && THREADS <= 1024, "level decomposition");
+  static_assert(!VADV || !RELOAD_T, "Eulerian branch keeps T in registers");
 
   __shared__ __attribute__((aligned(16))) double s_dvvT[64];
   __shared__ __attribute__((aligned(16))) double s_geo[G_SIZE];
   constexpr int SLOTS = BATCH ? 5 : 1;  // LDS tile slots per wave (BATCH: p, T, Ephi, vcov1, vcov0)
   __shared__ __attribute__((aligned(16))) double s_tile[WAVES * 64 * SLOTS];
-  __shared__ double s_park[3 * BLK];        // dp, u, v of every level, [field][lev][pt]
+  __shared__ double s_park[3 * BLK + (VADV ? PP : 0)];  // dp, u, v of every level, [field][lev][pt] (+ a zero row for VADV)
   __shared__ double s_tot_dp[WAVES * PP];   // per wave: sum of dp over its levels
   __shared__ double s_tot_div[WAVES * PP];  // ... of divdp
   __shared__ double s_tot_ht[WAVES * PP];   // ... of Rgas*T_v*dp/p
+  __shared__ double s_Thalo[VADV ? WAVES * 2 * PP : 1];  // VADV: T of each wave's first / last level
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -87,6 +93,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   // volatile reads: the compiler must not forward the parked values through registers
   const volatile double* const park_rd = park_dp;
   if (tid < 64) s_dvvT[(tid & 7) * NP + (tid >> 3)] = k.Dvv[tid];  // Dvv[k][j] -> dvvT[j][k]
+  if (VADV && tid < PP) s_park[3 * BLK + tid] = 0.0;
   for (int idx = tid; idx < G_SIZE; idx += THREADS) {
     const double* src;
     if (idx < G_SPHEREMP) src = k.fcor + ie * PP + idx;
@@ -138,6 +145,8 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
         divdp[r] = divergence_sphere<COEF_LDS>(c, lane, Dinv, metdet, rmetdet, rrearth, x.uv.x * x.dp, x.uv.y * x.dp);  // P:114-121
       }
       if (!RELOAD_T) T[r] = x.T;
+      if (VADV && r == 0) s_Thalo[(w * 2 + 0) * PP + pt] = x.T;
+      if (VADV && r == TPW - 1) s_Thalo[(w * 2 + 1) * PP + pt] = x.T;
       Tv[r] = MOIST ? x.T * (1.0 + k.rv_over_rd_m1 * (x.q * recip(x.dp))) : x.T;  // P:135,150-151
       run_dp += x.dp;
       run_div += divdp[r];
@@ -189,6 +198,9 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     base_dp += s_tot_dp[w2 * PP + pt];
     base_div += s_tot_div[w2 * PP + pt];
   }
+  double sdot_sum = base_div;  // VADV: column total of divdp (X:237)
+  if (VADV)
+    for (int w2 = w; w2 < WAVES; ++w2) sdot_sum += s_tot_div[w2 * PP + pt];
   double wave_ht;  // sum of the hydrostatic increments over this wave's levels
   {
     double run = base_dp, acc = 0.0;
@@ -271,29 +283,57 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     const double vgrad_p = ur * gp0 + vr * gp1;                        // P:111
     const double ckk = 0.5 * rp, ckl = rp;                             // P:333-334
     const double om = vgrad_p * rp - ckl * suml - ckk * divdp[r];      // P:325,336,348
+    double eta_lo = 0.0, eta_hi = 0.0, T_vadv = 0.0, u_vadv = 0.0, v_vadv = 0.0;
+    if (VADV) {
+      const int lev = lev0 + r;  // wave-uniform: hybi comes through scalar loads
+      // X:238-254: eta_dot(k+1) = hybi(k+1)*sdot_sum - sum_{l<=k} divdp(l); 0 at the top and the surface
+      const double e_lo = k.hybi[lev] * sdot_sum - suml;
+      const double e_hi = k.hybi[lev + 1] * sdot_sum - (suml + divdp[r]);
+      eta_lo = lev > 0 ? e_lo : 0.0;
+      eta_hi = lev < NLEV - 1 ? e_hi : 0.0;
+      const double half_rdp = 0.5 * recip(dpr);                        // X:118
+      const double facp = half_rdp * eta_hi, facm = half_rdp * eta_lo; // CaarFunctor.hpp:526-527
+      // Neighbouring levels, branch-free: at the top (bottom) level facm (facp) is exactly 0 and
+      // the "neighbour" is some other finite value of the park (its last row is a zero pad).
+      const int wu = w > 0 ? w - 1 : 0, wd = w < WAVES - 1 ? w + 1 : w;
+      const double T_up = r > 0 ? T[r > 0 ? r - 1 : 0] : s_Thalo[(wu * 2 + 1) * PP + pt];
+      const double T_dn = r < TPW - 1 ? T[r < TPW - 1 ? r + 1 : r] : s_Thalo[(wd * 2 + 0) * PP + pt];
+      const double u_up = park_rd[BLK + (r - 1) * PP], u_dn = park_rd[BLK + (r + 1) * PP];
+      const double v_up = park_rd[2 * BLK + (r - 1) * PP], v_dn = park_rd[2 * BLK + (r + 1) * PP];
+      // CaarFunctor.hpp:513-546
+      T_vadv = facp * (T_dn - Tr) + facm * (Tr - T_up);
+      u_vadv = facp * (u_dn - ur) + facm * (ur - u_up);
+      v_vadv = facp * (v_dn - vr) + facm * (vr - v_up);
+    }
     suml += divdp[r];                                                  // P:339
     const double vgrad_T = ur * gT0 + vr * gT1;                        // P:209
     const double gpterm = Tv[r] * rp;                                  // P:219
     const double glnps1 = k.Rgas * gpterm * gp0;                       // P:221
     const double glnps2 = k.Rgas * gpterm * gp1;                       // P:222
     const double fcor = geo[G_FCOR + pt], spheremp = geo[G_SPHEREMP + pt];
-    const double vtens1 = vr * (fcor + vort) - gE0 - glnps1;         // P:227
-    const double vtens2 = -ur * (fcor + vort) - gE1 - glnps2;        // P:228
-    const double ttens = -vgrad_T + k.kappa * Tv[r] * om;              // P:230
+    double vtens1 = vr * (fcor + vort) - gE0 - glnps1;               // P:227
+    double vtens2 = -ur * (fcor + vort) - gE1 - glnps2;              // P:228
+    double ttens = -vgrad_T + k.kappa * Tv[r] * om;                    // P:230
+    if (VADV) {
+      vtens1 = -u_vadv + vr * (fcor + vort) - gE0 - glnps1;            // X:326-328
+      vtens2 = -v_vadv - ur * (fcor + vort) - gE1 - glnps2;            // X:332-334
+      ttens = -T_vadv - vgrad_T + k.kappa * Tv[r] * om;                // X:338
+    }
 
     dbl2 vo;
     vo.x = spheremp * (cur.vnm1.x + k.dt2 * vtens1);                   // P:251
     vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);                   // P:252
     stream_store<SNT>(v_np1 + off, vo);
     stream_store<SNT>(T_np1 + off, spheremp * (cur.Tnm1 + k.dt2 * ttens));       // P:253
-    stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * divdp[r]));  // P:254
+    if (VADV) stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * (divdp[r] + eta_hi - eta_lo)));  // X:515-517
+    else stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * divdp[r]));  // P:254
     stream_store<SNT>(phi_out + off, phi);
     stream_store<SNT>(omega_p + off, cur.om + k.eta_ave_w * om);                 // P:173
     dbl2 vn;
     vn.x = cur.vn0.x + k.eta_ave_w * (ur * dpr);                       // P:117
     vn.y = cur.vn0.y + k.eta_ave_w * (vr * dpr);                       // P:118
     stream_store<SNT>(vn0 + off, vn);
-    stream_store<SNT>(eta + off, cur.eta + eta_zero);                   // P:172
+    stream_store<SNT>(eta + off, cur.eta + (VADV ? k.eta_ave_w * eta_lo : eta_zero));  // P:172, X:271-272
     cur = nxt;
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -304,6 +344,13 @@ template <int NLEV, int TPW, int MINW, bool NT, bool COEF_LDS = false, bool RELO
 static hipError_t launch_np8(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = NLEV / TPW * 64;
   const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
+  if (k.vadv) {  // rsplit == 0: T stays in registers (no RELOAD_T form)
+    if (k.qn0 >= 0)
+      hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT, COEF_LDS, false, BATCH, true>), dim3(grid), dim3(THREADS), 0, stream, k);
+    else
+      hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false, NT, COEF_LDS, false, BATCH, true>), dim3(grid), dim3(THREADS), 0, stream, k);
+    return hipGetLastError();
+  }
   if (k.qn0 >= 0)
     hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT, COEF_LDS, RELOAD_T, BATCH>), dim3(grid), dim3(THREADS), 0, stream, k);
   else  // dry branch (P:128-139)

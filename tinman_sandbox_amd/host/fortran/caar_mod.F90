@@ -31,6 +31,9 @@ module caar_mod
     integer(c_int) :: nets, nete, n0, np1, nm1, qn0
     real(c_double) :: dt2, rrearth, eta_ave_w, Rwater_vapor, Rgas, kappa, ps0, hyai0
     type(c_ptr)    :: Dvv      ! np*np doubles, C order: Dvv_c((i-1)*np + j) = deriv%Dvv(i,j)
+    integer(c_int) :: rsplit = 1          ! > 0: vertically Lagrangian (routine_mod.F90); 0: Eulerian
+    type(c_ptr)    :: hybi = c_null_ptr     ! hvcoord%hybi(1:nlev+1), read when rsplit == 0
+    type(c_ptr)    :: hybi_dev = c_null_ptr ! device copy for the stateless caar_launch only
   end type
 
   interface

@@ -82,6 +82,11 @@ CaarParams params_for(const TestData& d) {
   p.ps0 = d.hvcoord.ps0;
   p.hyai0 = d.hvcoord.hyai[0];
   p.Dvv = &d.deriv.Dvv[0][0];
+  // the reference's pointers_only Control has no rsplit: its path is the vertically
+  // Lagrangian one (P:22-28: eta_dot_dpdn, T_vadv, v_vadv = 0)
+  p.rsplit = 1;
+  p.hybi = nullptr;
+  p.hybi_dev = nullptr;
   return p;
 }
 
