@@ -50,6 +50,24 @@ def test_driver_prints_oracle_norms(np_, nlev, exe):
     assert np.allclose(blocks[3], after, rtol=1e-13, atol=0)
 
 
+def test_driver_eulerian_vertical_coordinate():
+    """--tinman-rsplit=0: DeviceSession::set_vertical_coordinate with hybi(k) = (k/nlev)^2;
+    norms against the oracle's rsplit == 0 branch (parity unpinned, oracle/caar_oracle.h)."""
+    path = os.path.join(ROOT, "tinman_sandbox_amd", "host", "caar_driver")
+    out = subprocess.run([path, "--tinman-num-elems=4", "--tinman-num-exec=1", "--tinman-rsplit=0"],
+                         check=True, capture_output=True, text=True, timeout=300).stdout
+    blocks = norms_in(out)
+    O = po.Oracle()
+    arrs = O.init_arrays(4, 72, 1, 3, 4)
+    sc = po.default_scalars(72)
+    sc.update(rsplit=0, hybi=(np.arange(73) / 72.0) ** 2)
+    O.compute_and_apply_rhs(arrs, O.dvv_np4(False), sc)
+    after = O.state_norms(arrs, O.dvv_np4(False), sc)
+    assert np.allclose(blocks[2], after, rtol=1e-13, atol=0)
+    lag = oracle_norms(4, 72, 4)[1]
+    assert not np.allclose(after, lag, rtol=1e-9, atol=0)  # the branch does change the result
+
+
 def test_driver_shards_elements_over_devices():
     """--tinman-num-devices: one DeviceSession + host thread per slab (on a one-GPU box the
     slabs share the GPU); norms must equal the unsharded oracle's."""

@@ -434,7 +434,10 @@ static int cu_count() {
   return n;
 }
 
-template <int NLEV, int TPW, int MINW, bool NT, int PF = 0, int PERSIST_WG_PER_CU = 0, bool ETA_COND = false>
+// VTPW/VMINW/VPF: the launch shape of the Eulerian (rsplit == 0) form, which holds more live
+// values per level and wants fewer, fatter waves (tools/eulerian_bench.py).
+template <int NLEV, int TPW, int MINW, bool NT, int PF = 0, int PERSIST_WG_PER_CU = 0, bool ETA_COND = false,
+          int VTPW = TPW, int VMINW = MINW, int VPF = PF>
 static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = (NLEV + 3) / 4 / TPW * 64;
   constexpr bool PERSIST = PERSIST_WG_PER_CU > 0;
@@ -443,12 +446,13 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
     grid = cu_count() * PERSIST_WG_PER_CU;
     if (grid > num_elems) grid = num_elems;
   }
-  if (k.vadv) {  // rsplit == 0: the plain (non-persistent, unconditional eta store) form of this shape
+  if (k.vadv) {  // rsplit == 0: the plain (non-persistent, unconditional eta store) form
+    constexpr int VTHREADS = (NLEV + 3) / 4 / VTPW * 64;
     if (PERSIST) grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
     if (k.qn0 >= 0)
-      hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true, NT, PF, false, false, true>), dim3(grid), dim3(THREADS), 0, stream, k);
+      hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, true, NT, VPF, false, false, true>), dim3(grid), dim3(VTHREADS), 0, stream, k);
     else
-      hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false, NT, PF, false, false, true>), dim3(grid), dim3(THREADS), 0, stream, k);
+      hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, false, NT, VPF, false, false, true>), dim3(grid), dim3(VTHREADS), 0, stream, k);
     return hipGetLastError();
   }
   if (k.qn0 >= 0)
@@ -464,8 +468,8 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
-    {"caar_np4_kernel<72, 2, 1, true, true, 1, false, false>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1>},
-    {"caar_np4_kernel<72, 2, 1, true, true, 1, false, true>", "9 waves x 2 tiles, nt; eta_dot_dpdn stored only where its bits change (skips the no-op write-back: NOT the contract traffic)", launch_np4<72, 2, 1, true, 1, 0, true>},
+    {"caar_np4_kernel<72, 2, 1, true, true, 1, false, false>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},
+    {"caar_np4_kernel<72, 2, 1, true, true, 1, false, true>", "9 waves x 2 tiles, nt; eta_dot_dpdn stored only where its bits change (skips the no-op write-back: NOT the contract traffic)", launch_np4<72, 2, 1, true, 1, 0, true, 3, 2, 0>},
     {"caar_np4_kernel<72, 3, 2, true, true, 1, true, false>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt", launch_np4<72, 3, 2, true, 1, 1>},
     {"caar_np4_kernel<72, 3, 2, true, true, 0, true, false>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt, update loads one tile ahead", launch_np4<72, 3, 2, true, 0, 1>},
     {"caar_np4_kernel<72, 2, 1, true, true, 0, false, false>", "9 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<72, 2, 1, true, 0>},
@@ -476,7 +480,7 @@ KernelVariant kNp4Nlev72[] = {
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
-    {"caar_np4_kernel<128, 4, 2, true, true, 1, false, false>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1>},
+    {"caar_np4_kernel<128, 4, 2, true, true, 1, false, false>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 1, 0>},
     {"caar_np4_kernel<128, 4, 2, true, true, 1, true, false>", "persistent (1 workgroup/CU), 8 waves x 4 tiles, nt", launch_np4<128, 4, 2, true, 1, 1>},
     {"caar_np4_kernel<128, 4, 2, true, true, 0, false, false>", "8 waves x 4 tiles, nt, update loads one tile ahead", launch_np4<128, 4, 2, true, 0>},
     {"caar_np4_kernel<128, 4, 2, true, false, 1, false, false>", "8 waves x 4 tiles, default cache policy", launch_np4<128, 4, 2, false, 1>},
@@ -489,7 +493,7 @@ int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 KernelVariant kNp4Nlev32[] = {{"caar_np4_kernel<32, 2, 1, true, true, 1, false, false>", "4 waves x 2 tiles, nt", launch_np4<32, 2, 1, true, 1>}};
 KernelVariant kNp4Nlev60[] = {{"caar_np4_kernel<60, 3, 1, true, true, 1, false, false>", "5 waves x 3 tiles, nt", launch_np4<60, 3, 1, true, 1>}};
 KernelVariant kNp4Nlev64[] = {{"caar_np4_kernel<64, 2, 1, true, true, 1, false, false>", "8 waves x 2 tiles, nt", launch_np4<64, 2, 1, true, 1>}};
-KernelVariant kNp4Nlev80[] = {{"caar_np4_kernel<80, 2, 1, true, true, 1, false, false>", "10 waves x 2 tiles, nt", launch_np4<80, 2, 1, true, 1>}};
+KernelVariant kNp4Nlev80[] = {{"caar_np4_kernel<80, 2, 1, true, true, 1, false, false>", "10 waves x 2 tiles, nt", launch_np4<80, 2, 1, true, 1, 0, false, 4, 2, 0>}};
 KernelVariant kNp4Nlev96[] = {{"caar_np4_kernel<96, 3, 1, true, true, 1, false, false>", "8 waves x 3 tiles, nt", launch_np4<96, 3, 1, true, 1>}};
 // level counts that are not a multiple of 4 (last tile partly empty)
 KernelVariant kNp4Nlev26[] = {{"caar_np4_kernel<26, 1, 1, true, true, 1, false, false>", "7 waves x 1 tile (last tile: 2 of 4 levels), nt", launch_np4<26, 1, 1, true, 1>}};

@@ -56,6 +56,8 @@ void usage() {
             << "|  --tinman-update-levels=val: rotate time levels between runs (default=no)|\n"
             << "|  --tinman-device=N         : first HIP device to run on (default=0)      |\n"
             << "|  --tinman-num-devices=N    : shard the elements over N GPUs (default=1)  |\n"
+            << "|  --tinman-rsplit=N         : 0 = Eulerian vertical coordinate with       |\n"
+            << "|                              hybi(k) = (k/nlev)^2; default 1: Lagrangian |\n"
             << "|  --tinman-host-arrays=val  : arrays stay in host memory, as in the       |\n"
             << "|                              reference's loop (default=no: GPU-resident) |\n"
             << "|  --tinman-help             : prints this message                         |\n"
@@ -67,7 +69,7 @@ void usage() {
 int main(int argc, char** argv) {
   using namespace Homme;
   bool dump_res = false, update_levels = false, host_arrays = false;
-  int num_exec = 1, device = 0, num_devices = 1;
+  int num_exec = 1, device = 0, num_devices = 1, rsplit = 1;
 
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
@@ -87,6 +89,8 @@ int main(int argc, char** argv) {
       num_exec = std::atoi(val);
     } else if (starts_with(a, "--tinman-device=")) {
       device = std::atoi(val);
+    } else if (starts_with(a, "--tinman-rsplit=")) {
+      rsplit = std::atoi(val);
     } else if (starts_with(a, "--tinman-num-devices=")) {
       num_devices = std::atoi(val);
     } else if (starts_with(a, "--tinman-dump-res=")) {
@@ -187,7 +191,12 @@ int main(int argc, char** argv) {
 
   std::cout << " --- Uploading " << num_elems << " elements to " << num_devices << " HIP device(s) starting at "
             << device << "...\n";
-  on_all([&](Shard& sh) { sh.gpu.reset(new DeviceSession(data, sh.first, sh.count, sh.device)); });
+  real hybi[nlev + 1];
+  for (int i = 0; i <= nlev; ++i) hybi[i] = (real(i) / nlev) * (real(i) / nlev);
+  on_all([&](Shard& sh) {
+    sh.gpu.reset(new DeviceSession(data, sh.first, sh.count, sh.device));
+    sh.gpu->set_vertical_coordinate(rsplit, hybi);
+  });
   print_device_norms();
 
   std::cout << " --- Performing computations... (" << num_exec << " executions of the main loop on "

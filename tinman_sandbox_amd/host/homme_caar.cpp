@@ -97,7 +97,7 @@ DeviceSession::DeviceSession(const TestData& data, int ne, int device)
     : DeviceSession(data, 0, ne, device) {}
 
 DeviceSession::DeviceSession(const TestData& data, int first_elem, int ne, int device)
-    : ctx_(nullptr), num_elems_(ne), first_elem_(first_elem) {
+    : ctx_(nullptr), num_elems_(ne), first_elem_(first_elem), rsplit_(1), hybi_() {
   const CaarDims d = dims_for(ne);
   if (!caar_supported(d.np, d.nlev)) check(CAAR_EUNSUPPORTED, "caar_supported(np, nlev)");
   check(caar_create(&ctx_, &d, device), "caar_create");
@@ -111,8 +111,15 @@ void DeviceSession::upload(const TestData& data) {
   check(caar_upload(ctx_, &h, 0, num_elems_), "caar_upload");
 }
 
+void DeviceSession::set_vertical_coordinate(int rsplit, const real* hybi) {
+  rsplit_ = rsplit;
+  if (hybi) std::memcpy(hybi_, hybi, sizeof(hybi_));
+}
+
 void DeviceSession::run(const TestData& data) {
-  const CaarParams p = params_for(data);
+  CaarParams p = params_for(data);
+  p.rsplit = rsplit_;
+  p.hybi = hybi_;
   check(caar_run(ctx_, &p), "caar_run");
 }
 
@@ -129,7 +136,9 @@ void DeviceSession::state_norms(const TestData& data, real out[3]) {
 }
 
 float DeviceSession::time_runs(const TestData& data, int reps) {
-  const CaarParams p = params_for(data);
+  CaarParams p = params_for(data);
+  p.rsplit = rsplit_;
+  p.hybi = hybi_;
   float ms = 0.f;
   check(caar_time_runs(ctx_, &p, reps, &ms), "caar_time_runs");
   return ms;

@@ -45,6 +45,11 @@ class DeviceSession {
 
   // host -> device copy of all 16 arrays again (after the host changed them)
   void upload(const TestData& data);
+  // Vertical coordinate of the following run() calls.  Default rsplit = 1: vertically
+  // Lagrangian, the reference's path (its pointers_only Control has no rsplit).  rsplit = 0:
+  // Eulerian (eta_dot_dpdn and vertical advection computed; routine_extracted.F90:224-262),
+  // hybi = nlev+1 interface coefficients, copied.  Parity of that branch is unpinned.
+  void set_vertical_coordinate(int rsplit, const real* hybi);
   // one compute_and_apply_rhs with data's current Control/Constants/HVCoord/Derivative;
   // asynchronous, ordered on the session's stream
   void run(const TestData& data);
@@ -60,6 +65,8 @@ class DeviceSession {
   CaarContext* ctx_;
   int num_elems_;
   int first_elem_;
+  int rsplit_;
+  real hybi_[nlev + 1];
 };
 
 }  // namespace Homme

@@ -32,5 +32,13 @@ for np_, nlev, E in ((4, 72, 10000), (4, 128, 12500), (8, 72, 20000)):
         ms = time_ms(data)
         out.append("rsplit=%d %.4f ms %.0f GB/s (%.1f%% of 8 TB/s)" % (rs, ms, bytes_ / ms / 1e6, bytes_ / ms / 8e7))
     print("np=%d nlev=%d E=%d: " % (np_, nlev, E) + " | ".join(out), flush=True)
+    lib = tsa.library().lib
+    data.control.rsplit = 0
+    for v in range(lib.caar_num_variants(np_, nlev)):  # the Eulerian form of every launch shape
+        lib.caar_select_variant(np_, nlev, v)
+        ms = time_ms(data)
+        print("    rsplit=0 variant %d  %.4f ms  %.0f GB/s  %s" % (v, ms, bytes_ / ms / 1e6,
+                                                                   lib.caar_variant_info(np_, nlev, v).decode()), flush=True)
+    lib.caar_select_variant(np_, nlev, 0)
     del data
     torch.cuda.empty_cache()
