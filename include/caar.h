@@ -104,8 +104,9 @@ typedef struct CaarParams {
                            * stateless caar_launch (as dvv_dev: the caller uploads it once)  */
 } CaarParams;
 
-/* 1 if a kernel is compiled for (np, nlev), else 0.  Compiled: np=4 with nlev 26, 30, 32, 60, 64, 72,
- * 80, 96, 128; np=8 with nlev 72. */
+/* 1 if a kernel exists for (np, nlev), else 0.  np=4: kernels specialised for nlev 26, 30, 32,
+ * 60, 64, 72, 80, 96, 128 and one with a run-time level count for every other nlev in 2..256
+ * (the reference builds any PLEV, config.h.in:3); np=8: nlev 72. */
 int caar_supported(int np, int nlev);
 /* CAAR_ABI_VERSION the library was built with. */
 int caar_abi_version(void);

@@ -42,7 +42,9 @@ def test_supported_variants_and_names(lib):
     assert lib.lib.caar_supported(5, 72) == 0
     for nlev in (26, 30, 32, 60, 64, 80, 96):
         assert lib.lib.caar_supported(4, nlev) == 1
-    assert lib.lib.caar_supported(4, 27) == 0 and lib.lib.caar_supported(8, 128) == 0
+    assert lib.lib.caar_supported(4, 27) == 1 and lib.lib.caar_supported(4, 256) == 1   # run-time level count
+    assert lib.lib.caar_supported(4, 1) == 0 and lib.lib.caar_supported(4, 257) == 0
+    assert lib.lib.caar_supported(8, 128) == 0
     assert b"caar" in lib.lib.caar_kernel_name(4, 72)
     assert lib.lib.caar_kernel_name(3, 3) is None
     assert lib.lib.caar_strerror(-2).decode().startswith("no kernel")

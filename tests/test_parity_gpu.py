@@ -413,3 +413,24 @@ def test_eulerian_needs_hybi():
     data.control.rsplit = -1
     with pytest.raises(tsa.caar.CaarError):
         tsa.compute_and_apply_rhs(data)
+
+
+@pytest.mark.parametrize("nlev", [2, 3, 5, 17, 50, 65, 100, 127, 129, 200, 256])
+def test_any_level_count_matches_oracle(oracle, nlev):
+    """NP=4 with a level count that has no kernel of its own: the kernel with a run-time level
+    count (up to 8 waves x 2/4/8 tiles, dead tiles and rows masked).  Both vertical
+    coordinates, moist and dry; nothing outside the element's arrays may be written."""
+    lib = tsa.library().lib
+    assert lib.caar_supported(4, nlev) and b"<0," in lib.caar_kernel_name(4, nlev)
+    arrs = cases.hashed_arrays(4, nlev, 3, seed=200 + nlev)
+    Dvv = cases.dvv_for(4)
+    for extra in (dict(), dict(qn0=-1, n0=2, np1=0, nm1=1), dict(rsplit=0), dict(rsplit=0, qn0=-1, nets=1, nete=3)):
+        sc = eulerian_scalars(nlev, rsplit=1)
+        sc.update(extra)
+        want = cases.copy_arrays(arrs)
+        oracle.compute_and_apply_rhs(want, Dvv, sc)
+        _, got = run_gpu(arrs, Dvv, sc)
+        check_outputs(got, want, sc, "anylev%d_%s" % (nlev, sorted(extra)))
+        for n in po.ARRAY_NAMES:
+            if n not in cases.OUTPUT_NAMES:
+                assert np.array_equal(got[n], arrs[n]), n

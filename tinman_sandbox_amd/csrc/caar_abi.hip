@@ -21,6 +21,7 @@ extern int kNp4Nlev128Count;
 extern KernelVariant kNp8Nlev72[];
 extern int kNp8Nlev72Count;
 extern KernelVariant kNp4Nlev32[], kNp4Nlev60[], kNp4Nlev64[], kNp4Nlev80[], kNp4Nlev96[], kNp4Nlev26[], kNp4Nlev30[];
+extern KernelVariant kNp4NlevAny[];
 hipError_t launch_state_norms(const double* v, const double* T, const double* dp, int np, int nlev,
                               int timelevels, int tl, int e0, int e1, double* out3_per_elem,
                               hipStream_t stream);
@@ -65,6 +66,9 @@ static Config* find_config(int np, int nlev) {
   Config* c = configs(&n);
   for (int i = 0; i < n; ++i)
     if (c[i].np == np && c[i].nlev == nlev) return &c[i];
+  // NP=4: any other level count runs the kernel compiled for a run-time count
+  static Config any = {4, 0, kNp4NlevAny, 1, 0};
+  if (np == 4 && nlev >= 2 && nlev <= 256) return &any;
   return nullptr;
 }
 }  // namespace caar
@@ -281,6 +285,7 @@ static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const Caar
   k.qn0 = p->qn0;
   k.qsize_d = dims->qsize_d;
   k.timelevels = dims->timelevels;
+  k.nlev = dims->nlev;
   k.dt2 = p->dt2;
   k.rrearth = p->rrearth;
   k.eta_ave_w = p->eta_ave_w;

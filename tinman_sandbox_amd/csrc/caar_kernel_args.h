@@ -34,6 +34,7 @@ struct KernelArgs {
   int n0, np1, nm1;
   int qn0;            // -1: dry
   int qsize_d, timelevels;
+  int nlev;           // vertical levels (read by the kernels compiled for a run-time level count)
   double dt2;
   double rrearth;
   double eta_ave_w;

@@ -75,28 +75,36 @@ enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, 
 // from the column total and the running sum of divdp, and the vertical advection of T and v, for
 // which T, u, v of the whole column are mirrored in LDS (the level above / below a lane's own).
 // No extra HBM traffic.  The reference never builds this branch: parity unpinned (oracle/caar_oracle.h).
-template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, int PF, bool PERSIST, bool ETA_COND, bool VADV = false>
-__global__ __launch_bounds__((NLEV + 3) / 4 / TPW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
+//
+// NLEV_T == 0: the level count is a run-time argument (k.nlev <= 32*TPW): the workgroup has
+// ceil(ceil(nlev/4)/TPW) waves, tiles and rows beyond the last level are dead (masked, see
+// RAGGED), LDS is sized for the largest count.  Serves every PLEV the reference can be
+// configured with (config.h.in:3) that has no kernel of its own.
+template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, int PF, bool PERSIST, bool ETA_COND, bool VADV = false>
+__global__ __launch_bounds__(NLEV_T ? (NLEV_T + 3) / 4 / TPW * 64 : 512, MINW) void caar_np4_kernel(const KernelArgs k) {
   constexpr int PP = 16;               // GLL points per level
-  constexpr int NT = (NLEV + 3) / 4;   // tiles per element (the last one partly empty if NLEV % 4 != 0)
-  constexpr bool RAGGED = NLEV % 4 != 0;
-  constexpr int WAVES = NT / TPW;
-  constexpr int THREADS = WAVES * 64;
-  constexpr int BLK = NLEV * PP;       // doubles in one scalar field block
-  static_assert(NT % TPW == 0, "tile decomposition");
+  constexpr bool DYN = NLEV_T == 0;
+  constexpr int NT_MAX = DYN ? 8 * TPW : (NLEV_T + 3) / 4;  // LDS sizing
+  const int NLEV = DYN ? k.nlev : NLEV_T;
+  // tiles per element incl. dead ones (the last live one partly empty if NLEV % 4 != 0)
+  const int NT = DYN ? (int)(blockDim.x >> 6) * TPW : NT_MAX;
+  constexpr bool RAGGED = DYN || NLEV_T % 4 != 0;
+  const int THREADS = DYN ? (int)blockDim.x : NT_MAX / TPW * 64;
+  const int BLK = NLEV * PP;           // doubles in one scalar field block
+  static_assert(DYN || NT_MAX % TPW == 0, "tile decomposition");
   static_assert(!RAGGED || !PERSIST, "ragged level counts: non-persistent form only");
   static_assert(!VADV || (!PERSIST && !ETA_COND), "Eulerian branch: plain form only");
 
   __shared__ double s_dvv[16];
   __shared__ double s_geo_buf[PERSIST ? 2 : 1][G_SIZE];  // double-buffered across elements
-  __shared__ double s_tot_dp[NT * PP];   // sum of dp over each tile
-  __shared__ double s_tot_div[NT * PP];  // sum of divdp over each tile
-  __shared__ double s_tot_ht[NT * PP];   // sum of Rgas*T_v*dp/p over each tile
+  __shared__ double s_tot_dp[NT_MAX * PP];   // sum of dp over each tile
+  __shared__ double s_tot_div[NT_MAX * PP];  // sum of divdp over each tile
+  __shared__ double s_tot_ht[NT_MAX * PP];   // sum of Rgas*T_v*dp/p over each tile
   // VADV: T, u, v at n0 of the whole column, [field][1 + level][pt] with a zero row above the
   // top level and below the bottom one (and room for the dead rows of a ragged last tile)
-  constexpr int COL = VADV ? (NT * 4 + 2) * PP : 1;
+  constexpr int COL = VADV ? (NT_MAX * 4 + 2) * PP : 1;
   __shared__ double s_col[3][COL];
-  __shared__ double s_hybi[VADV ? NT * 4 + 1 : 1];
+  __shared__ double s_hybi[VADV ? NT_MAX * 4 + 1 : 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -155,7 +163,7 @@ __global__ __launch_bounds__((NLEV + 3) / 4 / TPW * 64, MINW) void caar_np4_kern
     if (idx < G_DINV) return k.D + ie * PP * 4 + (idx - G_D);
     return k.Dinv + ie * PP * 4 + (idx - G_DINV);
   };
-  static_assert(!PERSIST || THREADS >= G_SIZE, "persistent form stages one metric value per thread");
+  static_assert(!PERSIST || NT_MAX / TPW * 64 >= G_SIZE, "persistent form stages one metric value per thread");
 
   // ---- phase 0: issue the n0 loads of the first element --------------------------------
   N0In in = load_n0((size_t)ie_s);
@@ -495,6 +503,29 @@ KernelVariant kNp4Nlev60[] = {{"caar_np4_kernel<60, 3, 1, true, true, 1, false, 
 KernelVariant kNp4Nlev64[] = {{"caar_np4_kernel<64, 2, 1, true, true, 1, false, false>", "8 waves x 2 tiles, nt", launch_np4<64, 2, 1, true, 1>}};
 KernelVariant kNp4Nlev80[] = {{"caar_np4_kernel<80, 2, 1, true, true, 1, false, false>", "10 waves x 2 tiles, nt", launch_np4<80, 2, 1, true, 1, 0, false, 4, 2, 0>}};
 KernelVariant kNp4Nlev96[] = {{"caar_np4_kernel<96, 3, 1, true, true, 1, false, false>", "8 waves x 3 tiles, nt", launch_np4<96, 3, 1, true, 1>}};
+// Any other level count up to 256: the kernel with a run-time level count (NLEV_T = 0).
+template <int TPW, int MINW, int PF>
+static hipError_t launch_np4_dyn_shape(const KernelArgs& k, int num_elems, hipStream_t stream) {
+  const int tiles = (k.nlev + 3) / 4, waves = (tiles + TPW - 1) / TPW;
+  const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
+  const dim3 block(waves * 64);
+  if (k.vadv) {
+    if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, MINW, true, true, 0, false, false, true>), dim3(grid), block, 0, stream, k);
+    else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, MINW, false, true, 0, false, false, true>), dim3(grid), block, 0, stream, k);
+  } else {
+    if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, MINW, true, true, PF, false, false>), dim3(grid), block, 0, stream, k);
+    else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, MINW, false, true, PF, false, false>), dim3(grid), block, 0, stream, k);
+  }
+  return hipGetLastError();
+}
+static hipError_t launch_np4_dyn(const KernelArgs& k, int num_elems, hipStream_t stream) {
+  if (k.nlev < 2 || k.nlev > 256) return hipErrorInvalidValue;
+  if (k.nlev <= 64) return launch_np4_dyn_shape<2, 1, 1>(k, num_elems, stream);   // <= 8 waves x 2 tiles
+  if (k.nlev <= 128) return launch_np4_dyn_shape<4, 1, 0>(k, num_elems, stream);  // <= 8 waves x 4 tiles
+  return launch_np4_dyn_shape<8, 1, 0>(k, num_elems, stream);                     // <= 8 waves x 8 tiles
+}
+KernelVariant kNp4NlevAny[] = {{"caar_np4_kernel<0, ...>", "run-time level count (2..256): up to 8 waves x 2/4/8 tiles, dead rows masked, nt", launch_np4_dyn}};
+
 // level counts that are not a multiple of 4 (last tile partly empty)
 KernelVariant kNp4Nlev26[] = {{"caar_np4_kernel<26, 1, 1, true, true, 1, false, false>", "7 waves x 1 tile (last tile: 2 of 4 levels), nt", launch_np4<26, 1, 1, true, 1>}};
 KernelVariant kNp4Nlev30[] = {{"caar_np4_kernel<30, 2, 1, true, true, 1, false, false>", "4 waves x 2 tiles (last tile: 2 of 4 levels), nt", launch_np4<30, 2, 1, true, 1>}};
