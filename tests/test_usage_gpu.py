@@ -213,3 +213,45 @@ def test_whole_job_on_one_gpu_beyond_4gib_offsets(oracle, np_, nlev, E):
         assert abs(got_norm - float(torch.sqrt((x * x).sum()))) <= 1e-12 * got_norm, name
     del data
     torch.cuda.empty_cache()
+
+
+def test_disjoint_element_ranges_on_concurrent_streams(oracle):
+    """HOMME's horizontal threading: several callers, each with its own Control{nets, nete}
+    (data_structures.hpp:58-69), on disjoint element ranges of the same arrays.  Three
+    streams at once must give bit for bit what one launch over the whole range gives."""
+    arrs = cases.hashed_arrays(4, 72, 300, seed=211)
+    Dvv = cases.dvv_for(4)
+    sc = po.default_scalars(72)
+    sc.update(qn0=1, dt2=0.5)
+    whole = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    tsa.compute_and_apply_rhs(whole)
+    torch.cuda.synchronize()
+    want = whole.arrays.to_numpy()
+
+    data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    data.dvv_device()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    cuts = [0, 77, 201, 300]
+    for rep in range(1):
+        for s, (a, b) in zip(streams, zip(cuts[:-1], cuts[1:])):
+            data.control.nets, data.control.nete = a, b
+            tsa.compute_and_apply_rhs(data, s)
+    torch.cuda.synchronize()
+    got = data.arrays.to_numpy()
+    for n in tsa.ARRAY_NAMES:
+        assert np.array_equal(got[n], want[n]), n
+
+
+def test_misaligned_arrays_are_refused():
+    """v and vn0 move as 16-byte (u, v) pairs: a base that is only 8-byte aligned is an error,
+    not a fault."""
+    import ctypes as C
+    from tinman_sandbox_amd import caar as m
+    L = tsa.library()
+    data = tsa.TestData().init_data(4, 4, 72, device="cuda")
+    dims, ptrs, prm = data.arrays.dims(), data.arrays.pointers(), data.params()
+    shifted = C.cast(C.c_void_p(data.arrays["elem_state_v"].data_ptr() + 8), m._dp)
+    ptrs.elem_state_v = shifted
+    rc = L.lib.caar_launch(C.byref(dims), C.byref(ptrs), C.c_void_p(data.dvv_device().data_ptr()), C.byref(prm), None)
+    assert rc == -1 and b"invalid" in L.lib.caar_strerror(rc)
