@@ -476,33 +476,33 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
-    {"caar_np4_kernel<72, 2, 1, true, true, 1, false, false>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},
-    {"caar_np4_kernel<72, 2, 1, true, true, 1, false, true>", "9 waves x 2 tiles, nt; eta_dot_dpdn stored only where its bits change (skips the no-op write-back: NOT the contract traffic)", launch_np4<72, 2, 1, true, 1, 0, true, 3, 2, 0>},
-    {"caar_np4_kernel<72, 3, 2, true, true, 1, true, false>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt", launch_np4<72, 3, 2, true, 1, 1>},
-    {"caar_np4_kernel<72, 3, 2, true, true, 0, true, false>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt, update loads one tile ahead", launch_np4<72, 3, 2, true, 0, 1>},
-    {"caar_np4_kernel<72, 2, 1, true, true, 0, false, false>", "9 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<72, 2, 1, true, 0>},
-    {"caar_np4_kernel<72, 2, 1, true, false, 1, false, false>", "9 waves x 2 tiles, default cache policy", launch_np4<72, 2, 1, false, 1>},
-    {"caar_np4_kernel<72, 3, 2, true, true, 1, false, false>", "6 waves x 3 tiles, nt, update loads before the last barrier", launch_np4<72, 3, 2, true, 1>},
-    {"caar_np4_kernel<72, 6, 1, true, true, 0, false, false>", "3 waves x 6 tiles, nt", launch_np4<72, 6, 1, true, 0>},
+    {"caar_np4_kernel<72, 2, 1, true, true, 1, false, false, false>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},
+    {"caar_np4_kernel<72, 2, 1, true, true, 1, false, true, false>", "9 waves x 2 tiles, nt; eta_dot_dpdn stored only where its bits change (skips the no-op write-back: NOT the contract traffic)", launch_np4<72, 2, 1, true, 1, 0, true, 3, 2, 0>},
+    {"caar_np4_kernel<72, 3, 2, true, true, 1, true, false, false>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt", launch_np4<72, 3, 2, true, 1, 1>},
+    {"caar_np4_kernel<72, 3, 2, true, true, 0, true, false, false>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt, update loads one tile ahead", launch_np4<72, 3, 2, true, 0, 1>},
+    {"caar_np4_kernel<72, 2, 1, true, true, 0, false, false, false>", "9 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<72, 2, 1, true, 0>},
+    {"caar_np4_kernel<72, 2, 1, true, false, 1, false, false, false>", "9 waves x 2 tiles, default cache policy", launch_np4<72, 2, 1, false, 1>},
+    {"caar_np4_kernel<72, 3, 2, true, true, 1, false, false, false>", "6 waves x 3 tiles, nt, update loads before the last barrier", launch_np4<72, 3, 2, true, 1>},
+    {"caar_np4_kernel<72, 6, 1, true, true, 0, false, false, false>", "3 waves x 6 tiles, nt", launch_np4<72, 6, 1, true, 0>},
 };
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
-    {"caar_np4_kernel<128, 4, 2, true, true, 1, false, false>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 1, 0>},
-    {"caar_np4_kernel<128, 4, 2, true, true, 1, true, false>", "persistent (1 workgroup/CU), 8 waves x 4 tiles, nt", launch_np4<128, 4, 2, true, 1, 1>},
-    {"caar_np4_kernel<128, 4, 2, true, true, 0, false, false>", "8 waves x 4 tiles, nt, update loads one tile ahead", launch_np4<128, 4, 2, true, 0>},
-    {"caar_np4_kernel<128, 4, 2, true, false, 1, false, false>", "8 waves x 4 tiles, default cache policy", launch_np4<128, 4, 2, false, 1>},
-    {"caar_np4_kernel<128, 8, 1, true, true, 0, false, false>", "4 waves x 8 tiles, nt", launch_np4<128, 8, 1, true, 0>},
+    {"caar_np4_kernel<128, 4, 2, true, true, 1, false, false, false>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 1, 0>},
+    {"caar_np4_kernel<128, 4, 2, true, true, 1, true, false, false>", "persistent (1 workgroup/CU), 8 waves x 4 tiles, nt", launch_np4<128, 4, 2, true, 1, 1>},
+    {"caar_np4_kernel<128, 4, 2, true, true, 0, false, false, false>", "8 waves x 4 tiles, nt, update loads one tile ahead", launch_np4<128, 4, 2, true, 0>},
+    {"caar_np4_kernel<128, 4, 2, true, false, 1, false, false, false>", "8 waves x 4 tiles, default cache policy", launch_np4<128, 4, 2, false, 1>},
+    {"caar_np4_kernel<128, 8, 1, true, true, 0, false, false, false>", "4 waves x 8 tiles, nt", launch_np4<128, 8, 1, true, 0>},
 };
 int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 
 // Other level counts HOMME configurations use (the reference builds any PLEV from config.h):
 // one launch shape each, same kernel template.
-KernelVariant kNp4Nlev32[] = {{"caar_np4_kernel<32, 2, 1, true, true, 1, false, false>", "4 waves x 2 tiles, nt", launch_np4<32, 2, 1, true, 1>}};
-KernelVariant kNp4Nlev60[] = {{"caar_np4_kernel<60, 3, 1, true, true, 1, false, false>", "5 waves x 3 tiles, nt", launch_np4<60, 3, 1, true, 1>}};
-KernelVariant kNp4Nlev64[] = {{"caar_np4_kernel<64, 2, 1, true, true, 1, false, false>", "8 waves x 2 tiles, nt", launch_np4<64, 2, 1, true, 1>}};
-KernelVariant kNp4Nlev80[] = {{"caar_np4_kernel<80, 2, 1, true, true, 1, false, false>", "10 waves x 2 tiles, nt", launch_np4<80, 2, 1, true, 1, 0, false, 4, 2, 0>}};
-KernelVariant kNp4Nlev96[] = {{"caar_np4_kernel<96, 3, 1, true, true, 1, false, false>", "8 waves x 3 tiles, nt", launch_np4<96, 3, 1, true, 1>}};
+KernelVariant kNp4Nlev32[] = {{"caar_np4_kernel<32, 2, 1, true, true, 1, false, false, false>", "4 waves x 2 tiles, nt", launch_np4<32, 2, 1, true, 1>}};
+KernelVariant kNp4Nlev60[] = {{"caar_np4_kernel<60, 3, 1, true, true, 1, false, false, false>", "5 waves x 3 tiles, nt", launch_np4<60, 3, 1, true, 1>}};
+KernelVariant kNp4Nlev64[] = {{"caar_np4_kernel<64, 2, 1, true, true, 1, false, false, false>", "8 waves x 2 tiles, nt", launch_np4<64, 2, 1, true, 1>}};
+KernelVariant kNp4Nlev80[] = {{"caar_np4_kernel<80, 2, 1, true, true, 1, false, false, false>", "10 waves x 2 tiles, nt", launch_np4<80, 2, 1, true, 1, 0, false, 4, 2, 0>}};
+KernelVariant kNp4Nlev96[] = {{"caar_np4_kernel<96, 3, 1, true, true, 1, false, false, false>", "8 waves x 3 tiles, nt", launch_np4<96, 3, 1, true, 1>}};
 // Any other level count up to 256: the kernel with a run-time level count (NLEV_T = 0).
 template <int TPW, int MINW, int PF>
 static hipError_t launch_np4_dyn_shape(const KernelArgs& k, int num_elems, hipStream_t stream) {
@@ -524,10 +524,10 @@ static hipError_t launch_np4_dyn(const KernelArgs& k, int num_elems, hipStream_t
   if (k.nlev <= 128) return launch_np4_dyn_shape<4, 1, 0>(k, num_elems, stream);  // <= 8 waves x 4 tiles
   return launch_np4_dyn_shape<8, 1, 0>(k, num_elems, stream);                     // <= 8 waves x 8 tiles
 }
-KernelVariant kNp4NlevAny[] = {{"caar_np4_kernel<0, ...>", "run-time level count (2..256): up to 8 waves x 2/4/8 tiles, dead rows masked, nt", launch_np4_dyn}};
+KernelVariant kNp4NlevAny[] = {{"caar_np4_kernel<0, ..., false>", "run-time level count (2..256): up to 8 waves x 2/4/8 tiles, dead rows masked, nt", launch_np4_dyn}};
 
 // level counts that are not a multiple of 4 (last tile partly empty)
-KernelVariant kNp4Nlev26[] = {{"caar_np4_kernel<26, 1, 1, true, true, 1, false, false>", "7 waves x 1 tile (last tile: 2 of 4 levels), nt", launch_np4<26, 1, 1, true, 1>}};
-KernelVariant kNp4Nlev30[] = {{"caar_np4_kernel<30, 2, 1, true, true, 1, false, false>", "4 waves x 2 tiles (last tile: 2 of 4 levels), nt", launch_np4<30, 2, 1, true, 1>}};
+KernelVariant kNp4Nlev26[] = {{"caar_np4_kernel<26, 1, 1, true, true, 1, false, false, false>", "7 waves x 1 tile (last tile: 2 of 4 levels), nt", launch_np4<26, 1, 1, true, 1>}};
+KernelVariant kNp4Nlev30[] = {{"caar_np4_kernel<30, 2, 1, true, true, 1, false, false, false>", "4 waves x 2 tiles (last tile: 2 of 4 levels), nt", launch_np4<30, 2, 1, true, 1>}};
 
 }  // namespace caar

@@ -360,13 +360,13 @@ static hipError_t launch_np8(const KernelArgs& k, int num_elems, hipStream_t str
 
 // (non-const on purpose, see caar_np4.hip)
 KernelVariant kNp8Nlev72[] = {
-    {"caar_np8_kernel<72, 9, 1, true, true, true, false, false>", "8 waves x 9 levels, nt, Dvv slices re-read from LDS", launch_np8<72, 9, 1, true, true, false, false>},
-    {"caar_np8_kernel<72, 9, 1, true, true, true, false, true>", "8 waves x 9 levels, nt, Dvv slices from LDS, operators batched per level", launch_np8<72, 9, 1, true, true, false, true>},
-    {"caar_np8_kernel<72, 9, 1, true, true, true, true, true>", "8 waves x 9 levels, nt, Dvv slices from LDS, T re-read, operators batched", launch_np8<72, 9, 1, true, true, true, true>},
-    {"caar_np8_kernel<72, 9, 1, true, true, true, true, false>", "8 waves x 9 levels, nt, Dvv slices from LDS, T re-read in the last phase", launch_np8<72, 9, 1, true, true, true, false>},
-    {"caar_np8_kernel<72, 9, 1, true, true, false, false, false>", "8 waves x 9 levels, nt, Dvv slices in registers", launch_np8<72, 9, 1, true, false, false, false>},
-    {"caar_np8_kernel<72, 9, 1, true, false, true, false, false>", "8 waves x 9 levels, default cache policy", launch_np8<72, 9, 1, false, true, false, false>},
-    {"caar_np8_kernel<72, 18, 1, true, true, false, false, true>", "4 waves x 18 levels (one wave per SIMD), nt, operators batched", launch_np8<72, 18, 1, true, false, false, true>},
+    {"caar_np8_kernel<72, 9, 1, true, true, true, false, false, false>", "8 waves x 9 levels, nt, Dvv slices re-read from LDS", launch_np8<72, 9, 1, true, true, false, false>},
+    {"caar_np8_kernel<72, 9, 1, true, true, true, false, true, false>", "8 waves x 9 levels, nt, Dvv slices from LDS, operators batched per level", launch_np8<72, 9, 1, true, true, false, true>},
+    {"caar_np8_kernel<72, 9, 1, true, true, true, true, true, false>", "8 waves x 9 levels, nt, Dvv slices from LDS, T re-read, operators batched", launch_np8<72, 9, 1, true, true, true, true>},
+    {"caar_np8_kernel<72, 9, 1, true, true, true, true, false, false>", "8 waves x 9 levels, nt, Dvv slices from LDS, T re-read in the last phase", launch_np8<72, 9, 1, true, true, true, false>},
+    {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false>", "8 waves x 9 levels, nt, Dvv slices in registers", launch_np8<72, 9, 1, true, false, false, false>},
+    {"caar_np8_kernel<72, 9, 1, true, false, true, false, false, false>", "8 waves x 9 levels, default cache policy", launch_np8<72, 9, 1, false, true, false, false>},
+    {"caar_np8_kernel<72, 18, 1, true, true, false, false, true, false>", "4 waves x 18 levels (one wave per SIMD), nt, operators batched", launch_np8<72, 18, 1, true, false, false, true>},
 };
 int kNp8Nlev72Count = sizeof(kNp8Nlev72) / sizeof(kNp8Nlev72[0]);
 
