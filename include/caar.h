@@ -218,6 +218,14 @@ int caar_download_f90(CaarContext *ctx, const CaarArrays *f90_host, int e0, int 
 /* Enqueue one compute_and_apply_rhs on the context's device arrays
  * (params->Dvv is read from host memory and cached on the device). */
 int caar_run(CaarContext *ctx, const CaarParams *params);
+/* `nsteps` compute_and_apply_rhs calls as ONE hipGraph launch on the context stream — for
+ * hosts that step a small number of elements many times, where the per-call launch cost
+ * (not the kernel) sets the pace.  rotate != 0 applies TestData::update_time_levels
+ * (data_structures.cpp:174-180: np1, nm1, n0 <- nm1, n0, np1) between consecutive calls,
+ * starting from params' indices; the caller rotates its own Control nsteps-1 times
+ * afterwards, as after nsteps-1 single calls.  The graph is captured on first use and kept while
+ * params, nsteps and rotate stay the same.  Asynchronous. */
+int caar_run_steps(CaarContext *ctx, const CaarParams *params, int nsteps, int rotate);
 /* Wait for everything enqueued on the context stream. */
 int caar_sync(CaarContext *ctx);
 /* Device pointers / stream of the context (for callers that launch their own work). */

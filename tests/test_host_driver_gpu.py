@@ -50,6 +50,20 @@ def test_driver_prints_oracle_norms(np_, nlev, exe):
     assert np.allclose(blocks[3], after, rtol=1e-13, atol=0)
 
 
+@pytest.mark.parametrize("rotate", ["no", "yes"])
+def test_driver_graph_of_steps_matches_single_launches(rotate):
+    """--tinman-graph=yes: DeviceSession::run_steps = caar_run_steps, all executions in one
+    hipGraph launch, with and without TestData::update_time_levels between them; the norms
+    must be the ones the launch-by-launch loop prints."""
+    path = os.path.join(ROOT, "tinman_sandbox_amd", "host", "caar_driver")
+    common = [path, "--tinman-num-elems=9", "--tinman-num-exec=4", "--tinman-update-levels=" + rotate]
+    a = subprocess.run(common + ["--tinman-graph=no"], check=True, capture_output=True, text=True, timeout=300).stdout
+    b = subprocess.run(common + ["--tinman-graph=yes"], check=True, capture_output=True, text=True, timeout=300).stdout
+    na, nb = norms_in(a), norms_in(b)
+    assert len(na) == 4 and len(nb) == 4, (a, b)
+    assert na == nb  # the same kernels on the same data: digit for digit
+
+
 def test_driver_eulerian_vertical_coordinate():
     """--tinman-rsplit=0: DeviceSession::set_vertical_coordinate with hybi(k) = (k/nlev)^2;
     norms against the oracle's rsplit == 0 branch (parity unpinned, oracle/caar_oracle.h)."""

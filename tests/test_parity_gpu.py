@@ -434,3 +434,37 @@ def test_any_level_count_matches_oracle(oracle, nlev):
         for n in po.ARRAY_NAMES:
             if n not in cases.OUTPUT_NAMES:
                 assert np.array_equal(got[n], arrs[n]), n
+
+
+def test_graph_of_steps_through_the_context_api(oracle):
+    """caar_run_steps: n calls as one hipGraph launch, rotating time levels between them like
+    TestData::update_time_levels; re-used while the parameters stay the same, re-captured when
+    they change (dt2 here)."""
+    import ctypes as C
+    from tinman_sandbox_amd import caar as m
+    L = tsa.library()
+    arrs, Dvv, sc = cases.make_case("np4_nlev72_hashed")
+    sc["dt2"] = 0.25
+    ne = arrs["elem_fcor"].shape[0]
+    dims = m._CaarDims(4, 72, 1, 3, ne)
+    ctx = C.c_void_p()
+    L.check(L.lib.caar_create(C.byref(ctx), C.byref(dims), 0), "create")
+    try:
+        for dt2 in (0.25, 0.25, 0.5):
+            sc["dt2"] = dt2
+            want = cases.copy_arrays(arrs)
+            s = dict(sc)
+            for _ in range(4):
+                oracle.compute_and_apply_rhs(want, Dvv, s)
+                s["np1"], s["nm1"], s["n0"] = s["nm1"], s["n0"], s["np1"]
+            host = cases.copy_arrays(arrs)
+            ptrs = m._CaarArrays(*[host[n].ctypes.data_as(m._dp) for n in m.ARRAY_NAMES])
+            L.check(L.lib.caar_upload(ctx, C.byref(ptrs), 0, ne), "upload")
+            prm = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cpu").params()
+            L.check(L.lib.caar_run_steps(ctx, C.byref(prm), 4, 1), "run_steps")
+            L.check(L.lib.caar_download(ctx, C.byref(ptrs), 0, ne, 0), "download")
+            L.check(L.lib.caar_sync(ctx), "sync")
+            for n in tsa.caar.MUTATED:
+                assert cases.scaled_err(host[n], want[n]) <= 1e-11, (dt2, n)
+    finally:
+        L.lib.caar_destroy(ctx)

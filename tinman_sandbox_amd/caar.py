@@ -63,7 +63,7 @@ class CaarLibrary:
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
                "caar_variant_info", "caar_set_xcd_chunked", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_traffic_skeleton", "caar_create", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_download_f90",
                "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
-               "caar_time_runs", "caar_map_host", "caar_run_mapped", "caar_unmap_host")
+               "caar_time_runs", "caar_run_steps", "caar_map_host", "caar_run_mapped", "caar_unmap_host")
 
     def __init__(self, path=LIB_PATH):
         if not os.path.exists(path):
@@ -116,6 +116,7 @@ class CaarLibrary:
         L.caar_stream.restype = vp
         L.caar_state_norms.argtypes = [vp, C.c_int, C.c_int, C.c_int, _dp]
         L.caar_time_runs.argtypes = [vp, C.POINTER(_CaarParams), C.c_int, C.POINTER(C.c_float)]
+        L.caar_run_steps.argtypes = [vp, C.POINTER(_CaarParams), C.c_int, C.c_int]
         L.caar_map_host.argtypes = [C.POINTER(vp), C.POINTER(_CaarDims), C.POINTER(_CaarArrays), C.c_int]
         L.caar_run_mapped.argtypes = [vp, C.POINTER(_CaarParams)]
         L.caar_unmap_host.argtypes = [vp]

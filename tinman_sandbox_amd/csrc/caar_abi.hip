@@ -128,6 +128,12 @@ struct CaarContext {
   caar::HostConstants consts;  // Dvv and hybi on the device
   double* norms_dev;    // 3 * num_elems
   double* stage_dev;    // staging for Fortran-ordered host arrays (largest array), lazily allocated
+  // caar_run_steps: the captured graph and what it was captured for
+  hipGraphExec_t steps_exec;
+  CaarParams steps_params;
+  int steps_n, steps_rotate;
+  double steps_dvv[64];
+  std::vector<double>* steps_hybi;
 };
 
 static double** array_slot(CaarArrays* a, int i) { return reinterpret_cast<double**>(a) + i; }
@@ -409,6 +415,8 @@ void caar_destroy(CaarContext* c) {
   c->consts.destroy();
   if (c->norms_dev) (void)hipFree(c->norms_dev);
   if (c->stage_dev) (void)hipFree(c->stage_dev);
+  if (c->steps_exec) (void)hipGraphExecDestroy(c->steps_exec);
+  delete c->steps_hybi;
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -503,6 +511,71 @@ int caar_run(CaarContext* c, const CaarParams* p) {
   const double* dvv_dev = nullptr;
   HIP_TRY(c->consts.sync(c->dims, &q, c->stream, &dvv_dev));
   return caar_launch(&c->dims, &c->dev, dvv_dev, &q, c->stream);
+}
+
+int caar_run_steps(CaarContext* c, const CaarParams* p, int nsteps, int rotate) {
+  if (!c || !p || !p->Dvv || nsteps < 1) return CAAR_EINVAL;
+  if (p->rsplit == 0 && !p->hybi) return CAAR_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  CaarParams q = *p;
+  const double* dvv_dev = nullptr;
+  HIP_TRY(c->consts.sync(c->dims, &q, c->stream, &dvv_dev));  // uploads stay outside the graph
+  const size_t nd = sizeof(double) * c->dims.np * c->dims.np, nh = (size_t)c->dims.nlev + 1;
+  // the cached graph is valid for the same scalars AND the same Dvv / hybi VALUES (they are
+  // baked into device buffers the kernels read, so only their content matters)
+  bool same = c->steps_exec && c->steps_n == nsteps && c->steps_rotate == (rotate != 0) &&
+              std::memcmp(c->steps_dvv, p->Dvv, nd) == 0;
+  if (same) {
+    CaarParams a = c->steps_params, b = *p;
+    a.Dvv = b.Dvv = nullptr;
+    a.hybi = b.hybi = nullptr;
+    a.hybi_dev = b.hybi_dev = nullptr;
+    same = std::memcmp(&a, &b, sizeof(a)) == 0;
+  }
+  if (same && p->rsplit == 0)
+    same = c->steps_hybi && std::memcmp(c->steps_hybi->data(), p->hybi, sizeof(double) * nh) == 0;
+  if (!same) {
+    int rc = check_common(&c->dims, p);
+    if (rc) return rc;
+    if (c->steps_exec) {
+      (void)hipGraphExecDestroy(c->steps_exec);
+      c->steps_exec = nullptr;
+    }
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < nsteps && rc == CAAR_OK; ++i) {
+      rc = caar_launch(&c->dims, &c->dev, dvv_dev, &q, c->stream);
+      if (rotate) {  // data_structures.cpp:174-180
+        const int t = q.np1;
+        q.np1 = q.nm1;
+        q.nm1 = q.n0;
+        q.n0 = t;
+      }
+    }
+    hipError_t e = hipStreamEndCapture(c->stream, &graph);  // always end the capture, also after an error
+    if (rc != CAAR_OK) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    if (e != hipSuccess) return (int)e;
+    e = hipGraphInstantiate(&c->steps_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+      c->steps_exec = nullptr;
+      return (int)e;
+    }
+    c->steps_params = *p;
+    c->steps_n = nsteps;
+    c->steps_rotate = rotate != 0;
+    std::memcpy(c->steps_dvv, p->Dvv, nd);
+    if (p->rsplit == 0) {
+      if (!c->steps_hybi) c->steps_hybi = new (std::nothrow) std::vector<double>();
+      if (!c->steps_hybi) return CAAR_ENOMEM;
+      c->steps_hybi->assign(p->hybi, p->hybi + nh);
+    }
+  }
+  HIP_TRY(hipGraphLaunch(c->steps_exec, c->stream));
+  return CAAR_OK;
 }
 
 int caar_sync(CaarContext* c) {

@@ -123,6 +123,13 @@ void DeviceSession::run(const TestData& data) {
   check(caar_run(ctx_, &p), "caar_run");
 }
 
+void DeviceSession::run_steps(const TestData& data, int nsteps, bool rotate) {
+  CaarParams p = params_for(data);
+  p.rsplit = rsplit_;
+  p.hybi = hybi_;
+  check(caar_run_steps(ctx_, &p, nsteps, rotate ? 1 : 0), "caar_run_steps");
+}
+
 void DeviceSession::sync() { check(caar_sync(ctx_), "caar_sync"); }
 
 void DeviceSession::download(TestData& data, bool all_arrays) {

@@ -53,6 +53,9 @@ class DeviceSession {
   // one compute_and_apply_rhs with data's current Control/Constants/HVCoord/Derivative;
   // asynchronous, ordered on the session's stream
   void run(const TestData& data);
+  // `nsteps` runs as one hipGraph launch (caar_run_steps); rotate: TestData::update_time_levels
+  // between them.  The caller still rotates `data` itself nsteps-1 times afterwards.
+  void run_steps(const TestData& data, int nsteps, bool rotate);
   void sync();
   // copy the arrays the kernel mutates (all_arrays: every array) back into data's host arrays
   void download(TestData& data, bool all_arrays = false);
