@@ -64,7 +64,6 @@ def cpu_baseline(np_, nlev, seconds):
     kind "reference") when it was built, else oracle/caar_oracle.c (kind "port").
     Each thread owns a private slab + Control range, the reference's own sharding
     hook (data_structures.hpp:58-69)."""
-    import numpy as np
     from oracle import pyoracle as po
     cores = host_cores()
     use_ref = po.have_reference(np_, nlev)

@@ -14,7 +14,6 @@ import pytest
 import torch
 
 import cases
-from oracle import pyoracle as po
 
 import tinman_sandbox_amd as tsa
 from tinman_sandbox_amd import f90_layout as fl

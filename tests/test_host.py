@@ -6,9 +6,7 @@ import re
 
 import numpy as np
 import pytest
-import torch
 
-import cases
 from oracle import pyoracle as po
 
 import tinman_sandbox_amd as tsa

@@ -14,7 +14,6 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-import cases
 from oracle import pyoracle as po
 
 import tinman_sandbox_amd as tsa

@@ -8,7 +8,6 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import cases  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
