@@ -255,3 +255,35 @@ def test_misaligned_arrays_are_refused():
     ptrs.elem_state_v = shifted
     rc = L.lib.caar_launch(C.byref(dims), C.byref(ptrs), C.c_void_p(data.dvv_device().data_ptr()), C.byref(prm), None)
     assert rc == -1 and b"invalid" in L.lib.caar_strerror(rc)
+
+
+def test_half_the_hbm_in_one_launch(oracle):
+    """700 000 elements (130 GB resident, NP=4 NLEV=72) in one launch: state_v alone holds
+    4.8e9 doubles, so element offsets exceed 2^32 DOUBLES, not just 2^32 bytes.  Elements on
+    both sides of that mark and the last one are checked against the oracle."""
+    E = 700000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200 * 2 ** 30:
+        pytest.skip("needs 200 GiB of free HBM (array initialisation temporaries included)")
+    data = tsa.TestData().init_data(E, 4, 72, device="cuda")
+    data.control.qn0, data.control.dt2 = 0, 0.5
+    per_elem_v = data.arrays["elem_state_v"][0].numel()
+    mark = (1 << 32) // per_elem_v
+    assert mark + 1 < E
+    picks = [0, mark - 1, mark, mark + 1, E - 1]
+    sub = {n: data.arrays[n][picks].cpu().numpy().copy() for n in tsa.ARRAY_NAMES}
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    tsa.compute_and_apply_rhs(data)
+    b.record()
+    torch.cuda.synchronize()
+    sc = po.default_scalars(72)
+    sc.update(qn0=0, dt2=0.5)
+    oracle.compute_and_apply_rhs(sub, data.deriv.Dvv, sc)
+    for n in tsa.caar.MUTATED:
+        got = data.arrays[n][picks].cpu().numpy()
+        assert cases.scaled_err(got, sub[n]) <= 1e-12, n
+    print("700000 elements: %.2f ms, %.0f GB/s algorithmic" % (
+        a.elapsed_time(b), tsa.algorithmic_bytes(4, 72) * E / a.elapsed_time(b) / 1e6))
+    del data
+    torch.cuda.empty_cache()
