@@ -186,7 +186,7 @@ int caar_layout_to_f90(const CaarDims *dims, const CaarArrays *caar_dev, const C
 /* ---- measurement utilities (roofline context; never on the product path) ---------
  * caar_stream_copy: device copy of n_doubles with 8 or 16 bytes per lane — the measured
  * HBM ceiling next to the spec peak and the calibration run for the HBM PMC counters.
- * caar_traffic_skeleton: touches exactly the bytes caar_launch touches (NP=4), same
+ * caar_traffic_skeleton: touches exactly the bytes caar_launch touches (NP=4; NP=8 NLEV=72), same
  * addressing and access widths, no arithmetic; it OVERWRITES the output arrays with
  * meaningless values.  `variant` picks the launch shape / cache policy being probed
  * (0 = the shape of the default kernel); unknown variants return hipErrorInvalidValue. */

@@ -35,6 +35,7 @@ hipError_t launch_reciprocal(const double* in, double* out, size_t n, hipStream_
 hipError_t launch_layout(double* dst, const double* src, size_t n, int np, int nc, int nlev, int qd,
                          int qdp_outer, bool to_caar, hipStream_t s);
 hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t stream);
+hipError_t launch_traffic_skeleton_np8(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t stream);
 
 struct Config {
   int np, nlev;
@@ -362,12 +363,14 @@ int caar_traffic_skeleton(const CaarDims* dims, const CaarArrays* dev, const Caa
                           void* stream) {
   int rc = check_common(dims, p);
   if (rc) return rc;
-  if (!dev || dims->np != 4) return CAAR_EUNSUPPORTED;
+  if (!dev || (dims->np != 4 && dims->np != 8)) return CAAR_EUNSUPPORTED;
   for (int i = 0; i < CAAR_NUM_ARRAYS; ++i)
     if (!*array_slot(dev, i)) return CAAR_EINVAL;
   if (p->nete == p->nets) return CAAR_OK;
   caar::KernelArgs k;
   fill_args_impl(k, dims, dev, nullptr, p);
+  if (dims->np == 8)
+    return (int)caar::launch_traffic_skeleton_np8(k, dims->nlev, variant, p->nete - p->nets, (hipStream_t)stream);
   return (int)caar::launch_traffic_skeleton(k, dims->nlev, variant, p->nete - p->nets, (hipStream_t)stream);
 }
 

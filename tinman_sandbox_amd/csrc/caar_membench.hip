@@ -65,10 +65,11 @@ __device__ __forceinline__ double2 ld2(const double2* p, bool) { return *p; }
 
 // NTL / NTS: cache policy of the loads / stores (0 default, 1 nt, 2 sc1); ALL_FIRST: issue every load of the element
 // before the first store (maximum bytes in flight) instead of tile by tile.
-template <int NLEV, int TPW, int NTL, int NTS, bool ALL_FIRST>
-__global__ __launch_bounds__(NLEV / 4 / TPW * 64) void traffic_skeleton_np4(const KernelArgs k) {
-  constexpr int PP = 16, BLK = NLEV * PP;
-  const int tid = threadIdx.x, lane = tid & 63, pt = lane & 15;
+// PP = 16: NP=4 (a 64-lane tile = 4 levels); PP = 64: NP=8 (a tile = one level).
+template <int NLEV, int TPW, int NTL, int NTS, bool ALL_FIRST, int PP = 16>
+__global__ __launch_bounds__(NLEV * PP / 64 / TPW * 64) void traffic_skeleton_np4(const KernelArgs k) {
+  constexpr int BLK = NLEV * PP;
+  const int tid = threadIdx.x, lane = tid & 63, pt = lane & (PP - 1);
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned ulane = lane;
   const long long ie_s = element_of_block(k, blockIdx.x);
@@ -226,6 +227,19 @@ hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, i
     }
   } else {
     return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// NP=8 NLEV=72: the launch shape of caar_np8_kernel (8 waves x 9 levels)
+hipError_t launch_traffic_skeleton_np8(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t s) {
+  if (nlev != 72) return hipErrorInvalidValue;
+  const dim3 grid(k.per_xcd ? 8 * k.per_xcd : num_elems), block(512);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((traffic_skeleton_np4<72, 9, 1, 1, false, 64>), grid, block, 0, s, k); break;
+    case 1: hipLaunchKernelGGL((traffic_skeleton_np4<72, 9, 0, 0, false, 64>), grid, block, 0, s, k); break;
+    case 2: hipLaunchKernelGGL((traffic_skeleton_np4<72, 9, 1, 1, true, 64>), grid, block, 0, s, k); break;
+    default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }

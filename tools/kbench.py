@@ -97,8 +97,8 @@ def main():
     times[("roundrobin", which[0])] = []  # default variant with the XCD-chunked element mapping
     times[("copy", 8)] = []
     times[("copy", 16)] = []
-    if a.np_ == 4:
-        for sv in range(a.skeletons):
+    if a.np_ == 4 or (a.np_ == 8 and a.nlev == 72):
+        for sv in range(min(a.skeletons, 3) if a.np_ == 8 else a.skeletons):
             times[("skeleton", sv)] = []
     for _ in range(a.rounds):
         for key in list(times):
