@@ -228,3 +228,32 @@ def test_eulerian_branch_conserves_column_mass(oracle):
     b = lag["elem_state_dp3d"][:, sc["np1"]].sum(axis=1)
     assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max()
     assert not np.array_equal(eul["elem_state_dp3d"], lag["elem_state_dp3d"])
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_numpy_restatement_agrees_with_the_c_oracle(oracle, name):
+    """oracle/np_oracle.py: the path restated a second time, by different code (whole-column
+    cumulative sums, einsum contractions), must land on the C oracle — which is bit-identical
+    to the reference — to rounding.  In 80-bit arithmetic it is the yardstick for the
+    rounding error of the reference itself (<= 1e-13 of the field magnitude on every case)."""
+    from oracle import np_oracle
+    arrs, out, sc = run_oracle(oracle, name)
+    Dvv = cases.make_case(name)[1]
+    for dtype, tol in ((np.float64, 2e-13), (np.longdouble, 1e-13)):
+        want = np_oracle.compute_and_apply_rhs(arrs, Dvv, sc, dtype=dtype)
+        for n in np_oracle.MUTATED:
+            err = float(np.abs(out[n] - want[n]).max() / max(np.abs(want[n]).max(), 1e-300))
+            assert err <= tol, (name, dtype.__name__, n, err)
+
+
+def test_numpy_restatement_eulerian_and_aliasing(oracle):
+    from oracle import np_oracle
+    arrs, Dvv, sc = eulerian_case(seed=152)
+    for extra in (dict(), dict(n0=1, np1=1, nm1=0), dict(qn0=-1, nets=1, nete=2)):
+        s = dict(sc, **extra)
+        got = cases.copy_arrays(arrs)
+        oracle.compute_and_apply_rhs(got, Dvv, s)
+        want = np_oracle.compute_and_apply_rhs(arrs, Dvv, s, dtype=np.longdouble)
+        for n in np_oracle.MUTATED:
+            err = float(np.abs(got[n] - want[n]).max() / max(np.abs(want[n]).max(), 1e-300))
+            assert err <= 1e-13, (sorted(extra), n, err)
