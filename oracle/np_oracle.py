@@ -1,5 +1,5 @@
 """Second, independent CPU restatement of compute_and_apply_rhs — vectorised numpy, any
-float dtype.  TEST INFRASTRUCTURE ONLY (imported by tests/ and tools/ only).
+float dtype.  TEST INFRASTRUCTURE ONLY (imported by tests/ only).
 
 Written from the mathematical statement of the path, not from
 oracle/caar_oracle.c: whole-column cumulative sums and einsum contractions instead of the
@@ -7,7 +7,7 @@ reference's loops, so its rounding differs from the reference's in the last bits
   * dtype=float64: cross-check of the C oracle by different code (tests/test_oracle.py);
   * dtype=numpy.longdouble (x87 80-bit, 64-bit mantissa): a higher-precision evaluation of
     the same formulas, against which the rounding error of the reference itself and of the
-    HIP kernels can be compared (tests/test_parity_gpu.py, tools/parity_report.py).
+    HIP kernels can be compared (tests/test_parity_gpu.py, tests/parity_report.py).
 Reference lines: P = cxx/pointers_only/compute_and_apply_rhs.cpp, S = sphere_operators.cpp,
 X = fortran/routine_extracted.F90, K = cxx/level_vectorized_ppscan/CaarFunctor.hpp.
 """

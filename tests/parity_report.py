@@ -4,13 +4,14 @@ against the CPU oracle: elementwise relative error and error scaled by the field
 max-abs, per output array; and, against an 80-bit evaluation of the same formulas
 (oracle/np_oracle.py with numpy.longdouble), the rounding error of the reference (= the
 oracle, bit-identical) next to the rounding error of the HIP path.
-(Diagnostic; the assertions live in tests/test_parity_gpu.py.)"""
+(Diagnostic, run by hand: `python tests/parity_report.py`; it lives under tests/ because it
+uses the oracle, which only test code may; the assertions are in tests/test_parity_gpu.py.)"""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # cases.py
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import cases  # noqa: E402

@@ -11,7 +11,7 @@ reference, fp64.  Applied to every output array in two forms:
     relative error is <= 3e-15, asserted below).
 The kernel uses FMA contraction, a Newton reciprocal (<= 1 ulp) for the divisions by
 p and dp3d, and blocked summation for the three vertical integrals, so results are
-not bit-identical to the reference; tools/parity_report.py prints the full table.
+not bit-identical to the reference; tests/parity_report.py prints the full table.
 """
 import numpy as np
 import pytest
