@@ -22,6 +22,7 @@ extern KernelVariant kNp8Nlev72[];
 extern int kNp8Nlev72Count;
 extern KernelVariant kNp4Nlev32[], kNp4Nlev60[], kNp4Nlev64[], kNp4Nlev80[], kNp4Nlev96[], kNp4Nlev26[], kNp4Nlev30[];
 extern KernelVariant kNp4NlevAny[];
+extern int kNp4Nlev32Count, kNp4Nlev60Count, kNp4Nlev64Count, kNp4Nlev80Count, kNp4Nlev96Count, kNp4Nlev26Count, kNp4Nlev30Count;
 hipError_t launch_state_norms(const double* v, const double* T, const double* dp, int np, int nlev,
                               int timelevels, int tl, int e0, int e1, double* out3_per_elem,
                               hipStream_t stream);
@@ -59,6 +60,13 @@ static Config* configs(int* n) {
   c[0].count = kNp4Nlev72Count;
   c[1].count = kNp4Nlev128Count;
   c[2].count = kNp8Nlev72Count;
+  c[3].count = kNp4Nlev32Count;
+  c[4].count = kNp4Nlev60Count;
+  c[5].count = kNp4Nlev64Count;
+  c[6].count = kNp4Nlev80Count;
+  c[7].count = kNp4Nlev96Count;
+  c[8].count = kNp4Nlev26Count;
+  c[9].count = kNp4Nlev30Count;
   *n = (int)(sizeof(c) / sizeof(c[0]));
   return c;
 }

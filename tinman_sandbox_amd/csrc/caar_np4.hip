@@ -76,15 +76,16 @@ enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, 
 // which T, u, v of the whole column are mirrored in LDS (the level above / below a lane's own).
 // No extra HBM traffic.  The reference never builds this branch: parity unpinned (oracle/caar_oracle.h).
 //
-// NLEV_T == 0: the level count is a run-time argument (k.nlev <= 32*TPW): the workgroup has
+// NLEV_T == 0: the level count is a run-time argument (k.nlev <= 4*DYNW*TPW): the workgroup has
 // ceil(ceil(nlev/4)/TPW) waves, tiles and rows beyond the last level are dead (masked, see
 // RAGGED), LDS is sized for the largest count.  Serves every PLEV the reference can be
 // configured with (config.h.in:3) that has no kernel of its own.
-template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, int PF, bool PERSIST, bool ETA_COND, bool VADV = false>
-__global__ __launch_bounds__(NLEV_T ? (NLEV_T + 3) / 4 / TPW * 64 : 512, MINW) void caar_np4_kernel(const KernelArgs k) {
+// DYNW: the most waves a workgroup of that form may have (its launch bound).
+template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, int PF, bool PERSIST, bool ETA_COND, bool VADV = false, int DYNW = 8>
+__global__ __launch_bounds__(NLEV_T ? (NLEV_T + 3) / 4 / TPW * 64 : DYNW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
   constexpr int PP = 16;               // GLL points per level
   constexpr bool DYN = NLEV_T == 0;
-  constexpr int NT_MAX = DYN ? 8 * TPW : (NLEV_T + 3) / 4;  // LDS sizing
+  constexpr int NT_MAX = DYN ? DYNW * TPW : (NLEV_T + 3) / 4;  // LDS sizing
   const int NLEV = DYN ? k.nlev : NLEV_T;
   // tiles per element incl. dead ones (the last live one partly empty if NLEV % 4 != 0)
   const int NT = DYN ? (int)(blockDim.x >> 6) * TPW : NT_MAX;
@@ -489,45 +490,92 @@ int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
     {"caar_np4_kernel<128, 4, 2, true, true, 1, false, false, false>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 1, 0>},
-    {"caar_np4_kernel<128, 4, 2, true, true, 1, true, false, false>", "persistent (1 workgroup/CU), 8 waves x 4 tiles, nt", launch_np4<128, 4, 2, true, 1, 1>},
     {"caar_np4_kernel<128, 4, 2, true, true, 0, false, false, false>", "8 waves x 4 tiles, nt, update loads one tile ahead", launch_np4<128, 4, 2, true, 0>},
     {"caar_np4_kernel<128, 4, 2, true, false, 1, false, false, false>", "8 waves x 4 tiles, default cache policy", launch_np4<128, 4, 2, false, 1>},
     {"caar_np4_kernel<128, 8, 1, true, true, 0, false, false, false>", "4 waves x 8 tiles, nt", launch_np4<128, 8, 1, true, 0>},
+    {"caar_np4_kernel<128, 2, 4, true, true, 0, false, false, false>", "16 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<128, 2, 4, true, 0, 0, false, 8, 1, 0>},
 };
 int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 
 // Other level counts HOMME configurations use (the reference builds any PLEV from config.h):
 // one launch shape each, same kernel template.
-KernelVariant kNp4Nlev32[] = {{"caar_np4_kernel<32, 2, 1, true, true, 1, false, false, false>", "4 waves x 2 tiles, nt", launch_np4<32, 2, 1, true, 1>}};
-KernelVariant kNp4Nlev60[] = {{"caar_np4_kernel<60, 3, 1, true, true, 1, false, false, false>", "5 waves x 3 tiles, nt", launch_np4<60, 3, 1, true, 1>}};
-KernelVariant kNp4Nlev64[] = {{"caar_np4_kernel<64, 2, 1, true, true, 1, false, false, false>", "8 waves x 2 tiles, nt", launch_np4<64, 2, 1, true, 1>}};
-KernelVariant kNp4Nlev80[] = {{"caar_np4_kernel<80, 2, 1, true, true, 1, false, false, false>", "10 waves x 2 tiles, nt", launch_np4<80, 2, 1, true, 1, 0, false, 4, 2, 0>}};
-KernelVariant kNp4Nlev96[] = {{"caar_np4_kernel<96, 3, 1, true, true, 1, false, false, false>", "8 waves x 3 tiles, nt", launch_np4<96, 3, 1, true, 1>}};
+KernelVariant kNp4Nlev32[] = {
+    {"caar_np4_kernel<32, 2, 1, true, true, 1, false, false, false>", "4 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<32, 2, 1, true, 1>},
+    {"caar_np4_kernel<32, 1, 2, true, true, 1, false, false, false>", "8 waves x 1 tile, room for 2 waves/SIMD, nt", launch_np4<32, 1, 2, true, 1>},
+    {"caar_np4_kernel<32, 2, 2, true, true, 1, false, false, false>", "4 waves x 2 tiles, room for 2 waves/SIMD, nt", launch_np4<32, 2, 2, true, 1>},
+    {"caar_np4_kernel<32, 1, 4, true, true, 1, false, false, false>", "8 waves x 1 tile, room for 4 waves/SIMD, nt", launch_np4<32, 1, 4, true, 1>},
+    {"caar_np4_kernel<32, 4, 1, true, true, 1, false, false, false>", "2 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<32, 4, 1, true, 1>},
+};
+int kNp4Nlev32Count = sizeof(kNp4Nlev32) / sizeof(kNp4Nlev32[0]);
+KernelVariant kNp4Nlev60[] = {
+    {"caar_np4_kernel<60, 1, 1, true, true, 1, false, false, false>", "15 waves x 1 tile, room for 1 wave/SIMD, nt", launch_np4<60, 1, 1, true, 1>},
+    {"caar_np4_kernel<60, 3, 1, true, true, 1, false, false, false>", "5 waves x 3 tiles, room for 1 wave/SIMD, nt", launch_np4<60, 3, 1, true, 1>},
+    {"caar_np4_kernel<60, 3, 2, true, true, 1, false, false, false>", "5 waves x 3 tiles, room for 2 waves/SIMD, nt", launch_np4<60, 3, 2, true, 1>},
+    {"caar_np4_kernel<60, 5, 1, true, true, 1, false, false, false>", "3 waves x 5 tiles, room for 1 wave/SIMD, nt", launch_np4<60, 5, 1, true, 1>},
+};
+int kNp4Nlev60Count = sizeof(kNp4Nlev60) / sizeof(kNp4Nlev60[0]);
+KernelVariant kNp4Nlev64[] = {
+    {"caar_np4_kernel<64, 4, 2, true, true, 1, false, false, false>", "4 waves x 4 tiles, room for 2 waves/SIMD, nt", launch_np4<64, 4, 2, true, 1>},
+    {"caar_np4_kernel<64, 2, 1, true, true, 1, false, false, false>", "8 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<64, 2, 1, true, 1>},
+    {"caar_np4_kernel<64, 2, 3, true, true, 1, false, false, false>", "8 waves x 2 tiles, room for 3 waves/SIMD, nt", launch_np4<64, 2, 3, true, 1>},
+    {"caar_np4_kernel<64, 4, 1, true, true, 1, false, false, false>", "4 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<64, 4, 1, true, 1>},
+    {"caar_np4_kernel<64, 1, 1, true, true, 1, false, false, false>", "16 waves x 1 tile, room for 1 wave/SIMD, nt", launch_np4<64, 1, 1, true, 1>},
+};
+int kNp4Nlev64Count = sizeof(kNp4Nlev64) / sizeof(kNp4Nlev64[0]);
+KernelVariant kNp4Nlev80[] = {
+    {"caar_np4_kernel<80, 2, 1, true, true, 1, false, false, false>", "10 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<80, 2, 1, true, 1, 0, false, 4, 2, 0>},
+    {"caar_np4_kernel<80, 4, 2, true, true, 1, false, false, false>", "5 waves x 4 tiles, room for 2 waves/SIMD, nt", launch_np4<80, 4, 2, true, 1, 0, false, 4, 2, 0>},
+    {"caar_np4_kernel<80, 5, 1, true, true, 1, false, false, false>", "4 waves x 5 tiles, room for 1 wave/SIMD, nt", launch_np4<80, 5, 1, true, 1, 0, false, 4, 2, 0>},
+    {"caar_np4_kernel<80, 4, 1, true, true, 1, false, false, false>", "5 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<80, 4, 1, true, 1, 0, false, 4, 2, 0>},
+};
+int kNp4Nlev80Count = sizeof(kNp4Nlev80) / sizeof(kNp4Nlev80[0]);
+KernelVariant kNp4Nlev96[] = {
+    {"caar_np4_kernel<96, 2, 1, true, true, 1, false, false, false>", "12 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<96, 2, 1, true, 1>},
+    {"caar_np4_kernel<96, 3, 1, true, true, 1, false, false, false>", "8 waves x 3 tiles, room for 1 wave/SIMD, nt", launch_np4<96, 3, 1, true, 1>},
+    {"caar_np4_kernel<96, 4, 2, true, true, 1, false, false, false>", "6 waves x 4 tiles, room for 2 waves/SIMD, nt", launch_np4<96, 4, 2, true, 1>},
+    {"caar_np4_kernel<96, 6, 1, true, true, 1, false, false, false>", "4 waves x 6 tiles, room for 1 wave/SIMD, nt", launch_np4<96, 6, 1, true, 1>},
+    {"caar_np4_kernel<96, 3, 2, true, true, 1, false, false, false>", "8 waves x 3 tiles, room for 2 waves/SIMD, nt", launch_np4<96, 3, 2, true, 1>},
+};
+int kNp4Nlev96Count = sizeof(kNp4Nlev96) / sizeof(kNp4Nlev96[0]);
 // Any other level count up to 256: the kernel with a run-time level count (NLEV_T = 0).
-template <int TPW, int MINW, int PF>
+template <int TPW, int MAXW, int PF, int VPF = 0>
 static hipError_t launch_np4_dyn_shape(const KernelArgs& k, int num_elems, hipStream_t stream) {
   const int tiles = (k.nlev + 3) / 4, waves = (tiles + TPW - 1) / TPW;
   const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
   const dim3 block(waves * 64);
+  if (waves > MAXW) return hipErrorInvalidValue;
   if (k.vadv) {
-    if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, MINW, true, true, 0, false, false, true>), dim3(grid), block, 0, stream, k);
-    else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, MINW, false, true, 0, false, false, true>), dim3(grid), block, 0, stream, k);
+    if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, true, true, VPF, false, false, true, MAXW>), dim3(grid), block, 0, stream, k);
+    else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, false, true, VPF, false, false, true, MAXW>), dim3(grid), block, 0, stream, k);
   } else {
-    if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, MINW, true, true, PF, false, false>), dim3(grid), block, 0, stream, k);
-    else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, MINW, false, true, PF, false, false>), dim3(grid), block, 0, stream, k);
+    if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, true, true, PF, false, false, false, MAXW>), dim3(grid), block, 0, stream, k);
+    else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, false, true, PF, false, false, false, MAXW>), dim3(grid), block, 0, stream, k);
   }
   return hipGetLastError();
 }
 static hipError_t launch_np4_dyn(const KernelArgs& k, int num_elems, hipStream_t stream) {
   if (k.nlev < 2 || k.nlev > 256) return hipErrorInvalidValue;
-  if (k.nlev <= 64) return launch_np4_dyn_shape<2, 1, 1>(k, num_elems, stream);   // <= 8 waves x 2 tiles
-  if (k.nlev <= 128) return launch_np4_dyn_shape<4, 1, 0>(k, num_elems, stream);  // <= 8 waves x 4 tiles
-  return launch_np4_dyn_shape<8, 1, 0>(k, num_elems, stream);                     // <= 8 waves x 8 tiles
+  if (k.nlev <= 64) return launch_np4_dyn_shape<2, 8, 1>(k, num_elems, stream);    // <= 8 waves x 2 tiles
+  if (k.nlev <= 128) return launch_np4_dyn_shape<4, 8, 0>(k, num_elems, stream);  // <= 8 waves x 4 tiles
+  return launch_np4_dyn_shape<8, 8, 0>(k, num_elems, stream);                     // <= 8 waves x 8 tiles
 }
-KernelVariant kNp4NlevAny[] = {{"caar_np4_kernel<0, ..., false>", "run-time level count (2..256): up to 8 waves x 2/4/8 tiles, dead rows masked, nt", launch_np4_dyn}};
+KernelVariant kNp4NlevAny[] = {{"caar_np4_kernel<0, ...>", "run-time level count (2..256): up to 8 waves x 2/4/8 tiles (12 x 2 measured slower: it spills under the 168-register cap), dead rows masked, nt", launch_np4_dyn}};
 
 // level counts that are not a multiple of 4 (last tile partly empty)
-KernelVariant kNp4Nlev26[] = {{"caar_np4_kernel<26, 1, 1, true, true, 1, false, false, false>", "7 waves x 1 tile (last tile: 2 of 4 levels), nt", launch_np4<26, 1, 1, true, 1>}};
-KernelVariant kNp4Nlev30[] = {{"caar_np4_kernel<30, 2, 1, true, true, 1, false, false, false>", "4 waves x 2 tiles (last tile: 2 of 4 levels), nt", launch_np4<30, 2, 1, true, 1>}};
+KernelVariant kNp4Nlev26[] = {
+    {"caar_np4_kernel<26, 7, 1, true, true, 1, false, false, false>", "1 waves x 7 tiles, room for 1 wave/SIMD, nt", launch_np4<26, 7, 1, true, 1>},
+    {"caar_np4_kernel<26, 1, 1, true, true, 1, false, false, false>", "7 waves x 1 tile, room for 1 wave/SIMD, nt", launch_np4<26, 1, 1, true, 1>},
+    {"caar_np4_kernel<26, 1, 3, true, true, 1, false, false, false>", "7 waves x 1 tile, room for 3 waves/SIMD, nt", launch_np4<26, 1, 3, true, 1>},
+    {"caar_np4_kernel<26, 1, 4, true, true, 1, false, false, false>", "7 waves x 1 tile, room for 4 waves/SIMD, nt", launch_np4<26, 1, 4, true, 1>},
+};
+int kNp4Nlev26Count = sizeof(kNp4Nlev26) / sizeof(kNp4Nlev26[0]);
+KernelVariant kNp4Nlev30[] = {
+    {"caar_np4_kernel<30, 2, 2, true, true, 1, false, false, false>", "4 waves x 2 tiles, room for 2 waves/SIMD, nt", launch_np4<30, 2, 2, true, 1>},
+    {"caar_np4_kernel<30, 2, 1, true, true, 1, false, false, false>", "4 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<30, 2, 1, true, 1>},
+    {"caar_np4_kernel<30, 1, 2, true, true, 1, false, false, false>", "8 waves x 1 tile, room for 2 waves/SIMD, nt", launch_np4<30, 1, 2, true, 1>},
+    {"caar_np4_kernel<30, 1, 4, true, true, 1, false, false, false>", "8 waves x 1 tile, room for 4 waves/SIMD, nt", launch_np4<30, 1, 4, true, 1>},
+    {"caar_np4_kernel<30, 4, 1, true, true, 1, false, false, false>", "2 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<30, 4, 1, true, 1>},
+};
+int kNp4Nlev30Count = sizeof(kNp4Nlev30) / sizeof(kNp4Nlev30[0]);
 
 }  // namespace caar
