@@ -143,6 +143,13 @@ int caar_sphere_operator(const CaarDims *dims, const CaarArrays *dev, const doub
                          int ie, int nlevels, const double *in_dev, double *out_dev, double rrearth,
                          void *stream);
 
+/* The same for the elements [e0, e1) in one launch: in [e][lev][np][np](,2) -> out
+ * [e][lev][np][np](,2), e = 0 .. e1-e0-1, `nlevels` fields per element (bandwidth-bound:
+ * every input byte read once, every output byte written once). */
+int caar_sphere_operator_range(const CaarDims *dims, const CaarArrays *dev, const double *dvv_dev, int which,
+                               int e0, int e1, int nlevels, const double *in_dev, double *out_dev,
+                               double rrearth, void *stream);
+
 /* Numerics hook: out[i] = the kernels' reciprocal of in[i] (v_rcp_f64 + two Newton steps,
  * used for the divisions by p and dp3d, P:150,219,291,323; <= 1 ulp for normal inputs). */
 int caar_reciprocal(const double *in_dev, double *out_dev, long long n, void *stream);

@@ -491,3 +491,36 @@ def test_rounding_error_is_no_larger_than_the_references(oracle, name):
                    for n in cases.OUTPUT_NAMES)
     e_ref, e_hip = worst(ref), worst(got)
     assert e_hip <= max(2.0 * e_ref, 1e-15), (e_hip, e_ref)
+
+
+@pytest.mark.parametrize("np_,nlev", [(4, 72), (8, 72)])
+def test_sphere_operators_over_an_element_range(oracle, np_, nlev):
+    """caar_sphere_operator_range: the three operators on every level of elements [e0, e1) in
+    one launch, against the oracle's operators (bit-identical to the reference's) and against
+    the one-element entry point (bit for bit: same device functions)."""
+    ne, nl = 5, 7
+    arrs = cases.hashed_arrays(np_, nlev, ne, seed=43)
+    Dvv = cases.dvv_for(np_, "double" if np_ == 4 else "gll")
+    sc = po.default_scalars(nlev)
+    sc["rrearth"] = 0.37
+    data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    e0, e1 = 1, 5
+    s = cases.uniform((e1 - e0, nl, np_, np_), 53, -3.0, 5.0)
+    v = cases.uniform((e1 - e0, nl, np_, np_, 2), 54, -3.0, 5.0)
+    sg, vg = torch.from_numpy(s).cuda(), torch.from_numpy(v).cuda()
+    g = tsa.sphere_operator_all(0, sg, data, e0, e1)
+    d = tsa.sphere_operator_all(1, vg, data, e0, e1)
+    w = tsa.sphere_operator_all(2, vg, data, e0, e1)
+    for e in range(e1 - e0):
+        ie = e0 + e
+        assert torch.equal(g[e], tsa.sphere_operator(0, sg[e], data, ie))
+        assert torch.equal(d[e], tsa.sphere_operator(1, vg[e], data, ie))
+        assert torch.equal(w[e], tsa.sphere_operator(2, vg[e], data, ie))
+        for k in range(nl):
+            wg = oracle.gradient_sphere(s[e, k], Dvv, arrs["elem_Dinv"][ie], 0.37)
+            wd = oracle.divergence_sphere(v[e, k], Dvv, arrs["elem_Dinv"][ie], arrs["elem_metdet"][ie],
+                                          arrs["elem_rmetdet"][ie], 0.37)
+            ww = oracle.vorticity_sphere(v[e, k], Dvv, arrs["elem_D"][ie], arrs["elem_rmetdet"][ie], 0.37)
+            assert cases.scaled_err(g[e, k].cpu().numpy(), wg) <= 1e-14, (ie, k)
+            assert cases.scaled_err(d[e, k].cpu().numpy(), wd) <= 1e-14, (ie, k)
+            assert cases.scaled_err(w[e, k].cpu().numpy(), ww) <= 1e-14, (ie, k)

@@ -59,7 +59,7 @@ class CaarLibrary:
     """ctypes view of libcaar_hip.so; every symbol of include/caar.h is bound here."""
 
     SYMBOLS = ("caar_supported", "caar_abi_version", "caar_device_count", "caar_strerror", "caar_array_len",
-               "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator", "caar_reciprocal",
+               "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator", "caar_sphere_operator_range", "caar_reciprocal",
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
                "caar_variant_info", "caar_set_xcd_chunked", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_traffic_skeleton", "caar_create", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_download_f90",
                "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
@@ -87,6 +87,8 @@ class CaarLibrary:
                                               C.c_int, C.c_int, vp, vp]
         L.caar_sphere_operator.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays), vp, C.c_int, C.c_int,
                                            C.c_int, vp, vp, C.c_double, vp]
+        L.caar_sphere_operator_range.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays), vp, C.c_int, C.c_int,
+                                                 C.c_int, C.c_int, vp, vp, C.c_double, vp]
         L.caar_reciprocal.argtypes = [vp, vp, C.c_longlong, vp]
         L.caar_kernel_name.argtypes = [C.c_int, C.c_int]
         L.caar_kernel_name.restype = C.c_char_p
@@ -473,6 +475,27 @@ def sphere_operator(which, field, data, ielem):
     L.check(L.lib.caar_sphere_operator(C.byref(dims), C.byref(ptrs), C.c_void_p(data.dvv_device().data_ptr()), which,
                                        ielem, nl, C.c_void_p(f.data_ptr()), C.c_void_p(out.data_ptr()),
                                        data.constants.rrearth, C.c_void_p(stream.cuda_stream)), "caar_sphere_operator")
+    return out
+
+
+def sphere_operator_all(which, field, data, e0=0, e1=None):
+    """The same operator on elements [e0, e1) in one launch: `field` is a device tensor
+    [e1-e0][nlevels][np][np] (gradient) or [e1-e0][nlevels][np][np][2]."""
+    L = library()
+    _require_gpu(data.arrays)
+    np_ = data.arrays.np
+    e1 = data.arrays.num_elems if e1 is None else e1
+    f = field.contiguous()
+    ne, nl = f.shape[0], f.shape[1]
+    want = (e1 - e0, nl, np_, np_) if which == 0 else (e1 - e0, nl, np_, np_, 2)
+    assert tuple(f.shape) == want and f.dtype == torch.float64
+    out = torch.empty((ne, nl, np_, np_, 2) if which == 0 else (ne, nl, np_, np_), dtype=torch.float64, device=f.device)
+    stream = torch.cuda.current_stream(data.arrays.device)
+    dims, ptrs = data.arrays.dims(), data.arrays.pointers()
+    L.check(L.lib.caar_sphere_operator_range(C.byref(dims), C.byref(ptrs), C.c_void_p(data.dvv_device().data_ptr()),
+                                             which, e0, e1, nl, C.c_void_p(f.data_ptr()), C.c_void_p(out.data_ptr()),
+                                             data.constants.rrearth, C.c_void_p(stream.cuda_stream)),
+            "caar_sphere_operator_range")
     return out
 
 

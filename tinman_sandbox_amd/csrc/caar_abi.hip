@@ -31,7 +31,7 @@ hipError_t launch_stream_copy(double* dst, const double* src, size_t n_doubles, 
                               hipStream_t stream);
 hipError_t launch_sphere_operator(int np, int which, const double* in, double* out, const double* D,
                                   const double* Dinv, const double* metdet, const double* rmetdet,
-                                  const double* dvv, int ie, int nlevels, double rrearth, hipStream_t s);
+                                  const double* dvv, int ie, int ne, int nlevels, double rrearth, hipStream_t s);
 hipError_t launch_reciprocal(const double* in, double* out, size_t n, hipStream_t s);
 hipError_t launch_layout(double* dst, const double* src, size_t n, int np, int nc, int nlev, int qd,
                          int qdp_outer, bool to_caar, hipStream_t s);
@@ -317,8 +317,20 @@ int caar_sphere_operator(const CaarDims* dims, const CaarArrays* dev, const doub
   if (dims->np != 4 && dims->np != 8) return CAAR_EUNSUPPORTED;
   if (!dev->elem_D || !dev->elem_Dinv || !dev->elem_metdet || !dev->elem_rmetdet) return CAAR_EINVAL;
   return (int)caar::launch_sphere_operator(dims->np, which, in_dev, out_dev, dev->elem_D, dev->elem_Dinv,
-                                           dev->elem_metdet, dev->elem_rmetdet, dvv_dev, ie, nlevels, rrearth,
+                                           dev->elem_metdet, dev->elem_rmetdet, dvv_dev, ie, 1, nlevels, rrearth,
                                            (hipStream_t)stream);
+}
+
+int caar_sphere_operator_range(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev, int which, int e0,
+                               int e1, int nlevels, const double* in_dev, double* out_dev, double rrearth,
+                               void* stream) {
+  if (!dims || !dev || !dvv_dev || !in_dev || !out_dev || which < 0 || which > 2 || nlevels < 0) return CAAR_EINVAL;
+  if (e0 < 0 || e1 > dims->num_elems || e0 > e1) return CAAR_EINVAL;
+  if (dims->np != 4 && dims->np != 8) return CAAR_EUNSUPPORTED;
+  if (!dev->elem_D || !dev->elem_Dinv || !dev->elem_metdet || !dev->elem_rmetdet) return CAAR_EINVAL;
+  return (int)caar::launch_sphere_operator(dims->np, which, in_dev, out_dev, dev->elem_D, dev->elem_Dinv,
+                                           dev->elem_metdet, dev->elem_rmetdet, dvv_dev, e0, e1 - e0, nlevels,
+                                           rrearth, (hipStream_t)stream);
 }
 
 int caar_reciprocal(const double* in_dev, double* out_dev, long long n, void* stream) {
