@@ -250,6 +250,20 @@ def main():
     from tinman_sandbox_amd import sharding
     wall_max, kernel_ms_max = sharding.max_over_ranks([wall, kernel_ms], dist, reduce_dev)
 
+    # per-launch spread (median and min), outside the timed region: one event pair per
+    # launch.  These intervals come out ~4 % shorter than the back-to-back average above: a launch
+    # that starts on an idle chip does not share HBM with the write-back of its predecessor's
+    # dirty cache lines.  The headline and roofline.achieved use the back-to-back figure.
+    per_launch = []
+    if rank == 0:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        for a, b in evs:
+            a.record(stream)
+            tsa.compute_and_apply_rhs(data, stream)
+            b.record(stream)
+        torch.cuda.synchronize(dev)
+        per_launch = sorted(a.elapsed_time(b) for a, b in evs)
+
     if rank == 0:
         balg = tsa.algorithmic_bytes(args.np_, args.nlev)
         per_launch_bytes = balg * (nete - nets)
@@ -293,6 +307,8 @@ def main():
                 "algorithmic_bytes_per_element": balg,
                 "elements_per_launch": nete - nets,
                 "kernel_ms": kernel_ms_max,
+                "kernel_ms_isolated_min": per_launch[0] if per_launch else None,
+                "kernel_ms_isolated_median": per_launch[len(per_launch) // 2] if per_launch else None,
             },
         }
         if world == 1 and not args.no_other_configs and (args.np_, args.nlev) == (4, 72):
