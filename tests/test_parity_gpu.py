@@ -524,3 +524,35 @@ def test_sphere_operators_over_an_element_range(oracle, np_, nlev):
             assert cases.scaled_err(g[e, k].cpu().numpy(), wg) <= 1e-14, (ie, k)
             assert cases.scaled_err(d[e, k].cpu().numpy(), wd) <= 1e-14, (ie, k)
             assert cases.scaled_err(w[e, k].cpu().numpy(), ww) <= 1e-14, (ie, k)
+
+
+@pytest.mark.parametrize("np_,nlev", [(4, 72), (8, 72), (4, 50)])
+def test_element_counts_and_workgroup_mappings(oracle, np_, nlev):
+    """Element counts around the sizes the launch logic cares about (1, one less / more than a
+    multiple of 8 and of the CU count) under both workgroup -> element mappings (round-robin
+    and XCD-chunked, whose grid is padded to a multiple of 8), every variant incl. the
+    persistent ones: each launch must touch exactly [nets, nete) and match the oracle."""
+    lib = tsa.library().lib
+    E = 521
+    arrs = cases.hashed_arrays(np_, nlev, E, seed=230 + np_ + nlev)
+    Dvv = cases.dvv_for(np_)
+    sc0 = po.default_scalars(nlev)
+    sc0.update(qn0=1, dt2=0.5)
+    want_all = cases.copy_arrays(arrs)
+    oracle.compute_and_apply_rhs(want_all, Dvv, sc0)     # elements are independent: slices of this are the answer
+    try:
+        for chunked in (0, 1):
+            lib.caar_set_xcd_chunked(chunked)
+            for v in range(lib.caar_num_variants(np_, nlev)):
+                lib.caar_select_variant(np_, nlev, v)
+                for nets, nete in ((0, 1), (3, 10), (5, 13), (0, 255), (1, 258), (8, 521), (0, 521)):
+                    sc = dict(sc0, nets=nets, nete=nete)
+                    _, got = run_gpu(arrs, Dvv, sc)
+                    for n in cases.OUTPUT_NAMES:
+                        g, w, a = got[n], want_all[n], arrs[n]
+                        assert cases.scaled_err(g[nets:nete], w[nets:nete]) <= RTOL, (chunked, v, nets, nete, n)
+                        assert np.array_equal(g[:nets], a[:nets]) and np.array_equal(g[nete:], a[nete:]), \
+                            (chunked, v, nets, nete, n)
+    finally:
+        lib.caar_set_xcd_chunked(0)
+        lib.caar_select_variant(np_, nlev, 0)
