@@ -205,12 +205,21 @@ int main(int argc, char** argv) {
 
   std::cout << " --- Performing computations... (" << num_exec << " executions of the main loop on "
             << num_elems << " elements)\n";
-  if (use_graph)  // capture outside the timed region; this first launch is a full set of executions,
-    on_all([&](Shard& sh) {  // undone for the printed state by re-uploading the initial arrays
+  // Untimed warm-up (clocks, TLBs, the graph capture): one full set of executions, undone for the
+  // printed state and the accumulators by re-uploading the initial arrays.
+  on_all([&](Shard& sh) {
+    if (use_graph) {
       sh.gpu->run_steps(sh.view, num_exec, update_levels);
-      sh.gpu->upload(data);
-      sh.gpu->sync();
-    });
+    } else {
+      TestData warm = sh.view;
+      for (int i = 0; i < num_exec; ++i) {
+        sh.gpu->run(warm);
+        if (update_levels && i + 1 < num_exec) warm.update_time_levels();
+      }
+    }
+    sh.gpu->upload(data);
+    sh.gpu->sync();
+  });
   const auto t0 = std::chrono::steady_clock::now();
   on_all([&](Shard& sh) {
     if (use_graph) {
