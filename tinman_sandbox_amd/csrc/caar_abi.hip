@@ -127,7 +127,9 @@ struct HostConstants {
 };
 }  // namespace caar
 
-static int g_xcd_chunked = 0;  // workgroup -> element mapping, see element_of_block()
+static int g_xcd_chunked = 0;
+// bytes of element data the hybrid cache policy keeps in the memory-side cache (0: none, all streaming)
+static long long g_cache_window = 160LL << 20;  // best of a 0..384 MB sweep at NLEV 72 and 128 (256 MB cache, shared with everything else)  // workgroup -> element mapping, see element_of_block()
 
 struct CaarContext {
   CaarDims dims;
@@ -185,6 +187,12 @@ int caar_select_variant(int np, int nlev, int variant) {
   if (!c) return CAAR_EUNSUPPORTED;
   if (variant < 0 || variant >= c->count) return CAAR_EINVAL;
   c->selected = variant;
+  return CAAR_OK;
+}
+
+int caar_set_cache_window(long long bytes) {
+  if (bytes < 0) return CAAR_EINVAL;
+  g_cache_window = bytes;
   return CAAR_OK;
 }
 
@@ -294,6 +302,14 @@ static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const Caar
   k.nets = p->nets;
   k.nelem = p->nete - p->nets;
   k.per_xcd = g_xcd_chunked ? (k.nelem + 7) / 8 : 0;
+  {
+    // distinct bytes one element update touches: ~0.8 x the algorithmic bytes (read-modify-write blocks once)
+    const long long per_elem = caar_algorithmic_bytes(dims->np, dims->nlev, p->qn0 < 0) * 4 / 5;
+    const long long n = per_elem > 0 ? g_cache_window / per_elem : 0;
+    // that many elements, spread evenly over the launch so that in steady state a constant share of the
+    // workgroups is served by the cache instead of HBM
+    k.cache_stride = n <= 0 ? 0 : (n >= k.nelem ? 1 : (int)((k.nelem + n - 1) / n));
+  }
   k.n0 = p->n0;
   k.np1 = p->np1;
   k.nm1 = p->nm1;

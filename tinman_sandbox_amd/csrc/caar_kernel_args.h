@@ -31,6 +31,7 @@ struct KernelArgs {
   int nets;           // first element of this launch
   int nelem;          // elements in this launch
   int per_xcd;        // 0: element = nets + blockIdx.x; else XCD-chunked mapping (element_of_block)
+  int cache_stride;   // hybrid cache policy: every cache_stride-th element of the launch uses the default policy (0: none)
   int n0, np1, nm1;
   int qn0;            // -1: dry
   int qsize_d, timelevels;

@@ -81,8 +81,9 @@ enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, 
 // RAGGED), LDS is sized for the largest count.  Serves every PLEV the reference can be
 // configured with (config.h.in:3) that has no kernel of its own.
 // DYNW: the most waves a workgroup of that form may have (its launch bound).
-template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, int PF, bool PERSIST, bool ETA_COND, bool VADV = false, int DYNW = 8>
-__global__ __launch_bounds__(NLEV_T ? (NLEV_T + 3) / 4 / TPW * 64 : DYNW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
+// SNT: non-temporal (streaming) loads and stores.
+template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW>
+__device__ __forceinline__ void caar_np4_element(const KernelArgs& k) {
   constexpr int PP = 16;               // GLL points per level
   constexpr bool DYN = NLEV_T == 0;
   constexpr int NT_MAX = DYN ? DYNW * TPW : (NLEV_T + 3) / 4;  // LDS sizing
@@ -431,6 +432,28 @@ __global__ __launch_bounds__(NLEV_T ? (NLEV_T + 3) / 4 / TPW * 64 : DYNW * 64, M
   }
 }
 
+// The kernel.  POL = cache policy of the element arrays' loads and stores:
+//   1  non-temporal: every array is touched once per launch, nothing is worth keeping (+0.4..5 % over 0);
+//   0  the default policy;
+//   2  hybrid: every k.cache_stride-th element of the launch uses the default policy, the rest stream
+//      non-temporally.  The streaming traffic does not allocate in the memory-side Infinity Cache
+//      (256 MB), so what the chosen elements leave there survives the rest of the launch — and
+//      the next call on the same arrays (a time-stepping host, the reference's driver loop) finds
+//      them there: reads and the read-modify-write accumulators of ~1 000 elements never reach HBM.
+//      Both code paths live in the kernel; the choice is uniform per workgroup.
+template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, bool PERSIST, bool ETA_COND, bool VADV = false, int DYNW = 8>
+__global__ __launch_bounds__(NLEV_T ? (NLEV_T + 3) / 4 / TPW * 64 : DYNW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
+  if constexpr (POL == 2) {
+    static_assert(!PERSIST && !VADV, "hybrid cache policy: plain vertically-Lagrangian form only");
+    const long long ie_s = element_of_block(k, blockIdx.x);
+    if (ie_s < 0) return;
+    if (k.cache_stride > 0 && (unsigned)(ie_s - k.nets) % (unsigned)k.cache_stride == 0) caar_np4_element<NLEV_T, TPW, MINW, MOIST, false, PF, PERSIST, ETA_COND, VADV, DYNW>(k);
+    else caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, PF, PERSIST, ETA_COND, VADV, DYNW>(k);
+  } else {
+    caar_np4_element<NLEV_T, TPW, MINW, MOIST, POL == 1, PF, PERSIST, ETA_COND, VADV, DYNW>(k);
+  }
+}
+
 // explicit instantiations + launchers --------------------------------------------------
 static int cu_count() {
   static int n = 0;
@@ -445,7 +468,7 @@ static int cu_count() {
 
 // VTPW/VMINW/VPF: the launch shape of the Eulerian (rsplit == 0) form, which holds more live
 // values per level and wants fewer, fatter waves (tools/eulerian_bench.py).
-template <int NLEV, int TPW, int MINW, bool NT, int PF = 0, int PERSIST_WG_PER_CU = 0, bool ETA_COND = false,
+template <int NLEV, int TPW, int MINW, int POL, int PF = 0, int PERSIST_WG_PER_CU = 0, bool ETA_COND = false,
           int VTPW = TPW, int VMINW = MINW, int VPF = PF>
 static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = (NLEV + 3) / 4 / TPW * 64;
@@ -459,15 +482,15 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
     constexpr int VTHREADS = (NLEV + 3) / 4 / VTPW * 64;
     if (PERSIST) grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
     if (k.qn0 >= 0)
-      hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, true, NT, VPF, false, false, true>), dim3(grid), dim3(VTHREADS), 0, stream, k);
+      hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, true, (POL != 0), VPF, false, false, true>), dim3(grid), dim3(VTHREADS), 0, stream, k);
     else
-      hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, false, NT, VPF, false, false, true>), dim3(grid), dim3(VTHREADS), 0, stream, k);
+      hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, false, (POL != 0), VPF, false, false, true>), dim3(grid), dim3(VTHREADS), 0, stream, k);
     return hipGetLastError();
   }
   if (k.qn0 >= 0)
-    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true, NT, PF, PERSIST, ETA_COND>), dim3(grid), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true, POL, PF, PERSIST, ETA_COND>), dim3(grid), dim3(THREADS), 0, stream, k);
   else  // dry branch (P:128-139): the Qdp block is never touched
-    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false, NT, PF, PERSIST, ETA_COND>), dim3(grid), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false, POL, PF, PERSIST, ETA_COND>), dim3(grid), dim3(THREADS), 0, stream, k);
   return hipGetLastError();
 }
 
@@ -477,64 +500,71 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
-    {"caar_np4_kernel<72, 2, 1, true, true, 1, false, false, false>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},
-    {"caar_np4_kernel<72, 2, 1, true, true, 1, false, true, false>", "9 waves x 2 tiles, nt; eta_dot_dpdn stored only where its bits change (skips the no-op write-back: NOT the contract traffic)", launch_np4<72, 2, 1, true, 1, 0, true, 3, 2, 0>},
-    {"caar_np4_kernel<72, 3, 2, true, true, 1, true, false, false>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt", launch_np4<72, 3, 2, true, 1, 1>},
-    {"caar_np4_kernel<72, 3, 2, true, true, 0, true, false, false>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt, update loads one tile ahead", launch_np4<72, 3, 2, true, 0, 1>},
-    {"caar_np4_kernel<72, 2, 1, true, true, 0, false, false, false>", "9 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<72, 2, 1, true, 0>},
-    {"caar_np4_kernel<72, 2, 1, true, false, 1, false, false, false>", "9 waves x 2 tiles, default cache policy", launch_np4<72, 2, 1, false, 1>},
-    {"caar_np4_kernel<72, 3, 2, true, true, 1, false, false, false>", "6 waves x 3 tiles, nt, update loads before the last barrier", launch_np4<72, 3, 2, true, 1>},
-    {"caar_np4_kernel<72, 6, 1, true, true, 0, false, false, false>", "3 waves x 6 tiles, nt", launch_np4<72, 6, 1, true, 0>},
+    {"caar_np4_kernel<72, 2, 1, true, 2, 1, false, false, false, 8>", "9 waves x 2 tiles, hybrid cache policy (every n-th element cached, bulk nt), update loads before the last barrier", launch_np4<72, 2, 1, 2, 1, 0, false, 3, 2, 0>},
+    {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, false, false, 8>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},
+    {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, true, false, 8>", "9 waves x 2 tiles, nt; eta_dot_dpdn stored only where its bits change (skips the no-op write-back: NOT the contract traffic)", launch_np4<72, 2, 1, true, 1, 0, true, 3, 2, 0>},
+    {"caar_np4_kernel<72, 3, 2, true, 1, 1, true, false, false, 8>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt", launch_np4<72, 3, 2, true, 1, 1>},
+    {"caar_np4_kernel<72, 3, 2, true, 1, 0, true, false, false, 8>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt, update loads one tile ahead", launch_np4<72, 3, 2, true, 0, 1>},
+    {"caar_np4_kernel<72, 2, 1, true, 1, 0, false, false, false, 8>", "9 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<72, 2, 1, true, 0>},
+    {"caar_np4_kernel<72, 2, 1, true, 0, 1, false, false, false, 8>", "9 waves x 2 tiles, default cache policy", launch_np4<72, 2, 1, false, 1>},
+    {"caar_np4_kernel<72, 3, 2, true, 1, 1, false, false, false, 8>", "6 waves x 3 tiles, nt, update loads before the last barrier", launch_np4<72, 3, 2, true, 1>},
+    {"caar_np4_kernel<72, 6, 1, true, 1, 0, false, false, false, 8>", "3 waves x 6 tiles, nt", launch_np4<72, 6, 1, true, 0>},
 };
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
-    {"caar_np4_kernel<128, 4, 2, true, true, 1, false, false, false>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 1, 0>},
-    {"caar_np4_kernel<128, 4, 2, true, true, 0, false, false, false>", "8 waves x 4 tiles, nt, update loads one tile ahead", launch_np4<128, 4, 2, true, 0>},
-    {"caar_np4_kernel<128, 4, 2, true, false, 1, false, false, false>", "8 waves x 4 tiles, default cache policy", launch_np4<128, 4, 2, false, 1>},
-    {"caar_np4_kernel<128, 8, 1, true, true, 0, false, false, false>", "4 waves x 8 tiles, nt", launch_np4<128, 8, 1, true, 0>},
-    {"caar_np4_kernel<128, 2, 4, true, true, 0, false, false, false>", "16 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<128, 2, 4, true, 0, 0, false, 8, 1, 0>},
+    {"caar_np4_kernel<128, 4, 2, true, 2, 1, false, false, false, 8>", "8 waves x 4 tiles, hybrid cache policy (every n-th element cached, bulk nt), update loads before the last barrier", launch_np4<128, 4, 2, 2, 1, 0, false, 8, 1, 0>},
+    {"caar_np4_kernel<128, 4, 2, true, 1, 1, false, false, false, 8>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 1, 0>},
+    {"caar_np4_kernel<128, 4, 2, true, 1, 0, false, false, false, 8>", "8 waves x 4 tiles, nt, update loads one tile ahead", launch_np4<128, 4, 2, true, 0>},
+    {"caar_np4_kernel<128, 4, 2, true, 0, 1, false, false, false, 8>", "8 waves x 4 tiles, default cache policy", launch_np4<128, 4, 2, false, 1>},
+    {"caar_np4_kernel<128, 8, 1, true, 1, 0, false, false, false, 8>", "4 waves x 8 tiles, nt", launch_np4<128, 8, 1, true, 0>},
+    {"caar_np4_kernel<128, 2, 4, true, 1, 0, false, false, false, 8>", "16 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<128, 2, 4, true, 0, 0, false, 8, 1, 0>},
 };
 int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 
 // Other level counts HOMME configurations use (the reference builds any PLEV from config.h):
 // one launch shape each, same kernel template.
 KernelVariant kNp4Nlev32[] = {
-    {"caar_np4_kernel<32, 2, 1, true, true, 1, false, false, false>", "4 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<32, 2, 1, true, 1>},
-    {"caar_np4_kernel<32, 1, 2, true, true, 1, false, false, false>", "8 waves x 1 tile, room for 2 waves/SIMD, nt", launch_np4<32, 1, 2, true, 1>},
-    {"caar_np4_kernel<32, 2, 2, true, true, 1, false, false, false>", "4 waves x 2 tiles, room for 2 waves/SIMD, nt", launch_np4<32, 2, 2, true, 1>},
-    {"caar_np4_kernel<32, 1, 4, true, true, 1, false, false, false>", "8 waves x 1 tile, room for 4 waves/SIMD, nt", launch_np4<32, 1, 4, true, 1>},
-    {"caar_np4_kernel<32, 4, 1, true, true, 1, false, false, false>", "2 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<32, 4, 1, true, 1>},
+    {"caar_np4_kernel<32, 2, 1, true, 2, 1, false, false, false, 8>", "4 waves x 2 tiles, room for 1 wave/SIMD, hybrid cache policy", launch_np4<32, 2, 1, 2, 1>},
+    {"caar_np4_kernel<32, 2, 1, true, 1, 1, false, false, false, 8>", "4 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<32, 2, 1, true, 1>},
+    {"caar_np4_kernel<32, 1, 2, true, 1, 1, false, false, false, 8>", "8 waves x 1 tile, room for 2 waves/SIMD, nt", launch_np4<32, 1, 2, true, 1>},
+    {"caar_np4_kernel<32, 2, 2, true, 1, 1, false, false, false, 8>", "4 waves x 2 tiles, room for 2 waves/SIMD, nt", launch_np4<32, 2, 2, true, 1>},
+    {"caar_np4_kernel<32, 1, 4, true, 1, 1, false, false, false, 8>", "8 waves x 1 tile, room for 4 waves/SIMD, nt", launch_np4<32, 1, 4, true, 1>},
+    {"caar_np4_kernel<32, 4, 1, true, 1, 1, false, false, false, 8>", "2 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<32, 4, 1, true, 1>},
 };
 int kNp4Nlev32Count = sizeof(kNp4Nlev32) / sizeof(kNp4Nlev32[0]);
 KernelVariant kNp4Nlev60[] = {
-    {"caar_np4_kernel<60, 1, 1, true, true, 1, false, false, false>", "15 waves x 1 tile, room for 1 wave/SIMD, nt", launch_np4<60, 1, 1, true, 1>},
-    {"caar_np4_kernel<60, 3, 1, true, true, 1, false, false, false>", "5 waves x 3 tiles, room for 1 wave/SIMD, nt", launch_np4<60, 3, 1, true, 1>},
-    {"caar_np4_kernel<60, 3, 2, true, true, 1, false, false, false>", "5 waves x 3 tiles, room for 2 waves/SIMD, nt", launch_np4<60, 3, 2, true, 1>},
-    {"caar_np4_kernel<60, 5, 1, true, true, 1, false, false, false>", "3 waves x 5 tiles, room for 1 wave/SIMD, nt", launch_np4<60, 5, 1, true, 1>},
+    {"caar_np4_kernel<60, 1, 1, true, 2, 1, false, false, false, 8>", "15 waves x 1 tile, room for 1 wave/SIMD, hybrid cache policy", launch_np4<60, 1, 1, 2, 1>},
+    {"caar_np4_kernel<60, 1, 1, true, 1, 1, false, false, false, 8>", "15 waves x 1 tile, room for 1 wave/SIMD, nt", launch_np4<60, 1, 1, true, 1>},
+    {"caar_np4_kernel<60, 3, 1, true, 1, 1, false, false, false, 8>", "5 waves x 3 tiles, room for 1 wave/SIMD, nt", launch_np4<60, 3, 1, true, 1>},
+    {"caar_np4_kernel<60, 3, 2, true, 1, 1, false, false, false, 8>", "5 waves x 3 tiles, room for 2 waves/SIMD, nt", launch_np4<60, 3, 2, true, 1>},
+    {"caar_np4_kernel<60, 5, 1, true, 1, 1, false, false, false, 8>", "3 waves x 5 tiles, room for 1 wave/SIMD, nt", launch_np4<60, 5, 1, true, 1>},
 };
 int kNp4Nlev60Count = sizeof(kNp4Nlev60) / sizeof(kNp4Nlev60[0]);
 KernelVariant kNp4Nlev64[] = {
-    {"caar_np4_kernel<64, 4, 2, true, true, 1, false, false, false>", "4 waves x 4 tiles, room for 2 waves/SIMD, nt", launch_np4<64, 4, 2, true, 1>},
-    {"caar_np4_kernel<64, 2, 1, true, true, 1, false, false, false>", "8 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<64, 2, 1, true, 1>},
-    {"caar_np4_kernel<64, 2, 3, true, true, 1, false, false, false>", "8 waves x 2 tiles, room for 3 waves/SIMD, nt", launch_np4<64, 2, 3, true, 1>},
-    {"caar_np4_kernel<64, 4, 1, true, true, 1, false, false, false>", "4 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<64, 4, 1, true, 1>},
-    {"caar_np4_kernel<64, 1, 1, true, true, 1, false, false, false>", "16 waves x 1 tile, room for 1 wave/SIMD, nt", launch_np4<64, 1, 1, true, 1>},
+    {"caar_np4_kernel<64, 4, 2, true, 2, 1, false, false, false, 8>", "4 waves x 4 tiles, room for 2 waves/SIMD, hybrid cache policy", launch_np4<64, 4, 2, 2, 1>},
+    {"caar_np4_kernel<64, 4, 2, true, 1, 1, false, false, false, 8>", "4 waves x 4 tiles, room for 2 waves/SIMD, nt", launch_np4<64, 4, 2, true, 1>},
+    {"caar_np4_kernel<64, 2, 1, true, 1, 1, false, false, false, 8>", "8 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<64, 2, 1, true, 1>},
+    {"caar_np4_kernel<64, 2, 3, true, 1, 1, false, false, false, 8>", "8 waves x 2 tiles, room for 3 waves/SIMD, nt", launch_np4<64, 2, 3, true, 1>},
+    {"caar_np4_kernel<64, 4, 1, true, 1, 1, false, false, false, 8>", "4 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<64, 4, 1, true, 1>},
+    {"caar_np4_kernel<64, 1, 1, true, 1, 1, false, false, false, 8>", "16 waves x 1 tile, room for 1 wave/SIMD, nt", launch_np4<64, 1, 1, true, 1>},
 };
 int kNp4Nlev64Count = sizeof(kNp4Nlev64) / sizeof(kNp4Nlev64[0]);
 KernelVariant kNp4Nlev80[] = {
-    {"caar_np4_kernel<80, 2, 1, true, true, 1, false, false, false>", "10 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<80, 2, 1, true, 1, 0, false, 4, 2, 0>},
-    {"caar_np4_kernel<80, 4, 2, true, true, 1, false, false, false>", "5 waves x 4 tiles, room for 2 waves/SIMD, nt", launch_np4<80, 4, 2, true, 1, 0, false, 4, 2, 0>},
-    {"caar_np4_kernel<80, 5, 1, true, true, 1, false, false, false>", "4 waves x 5 tiles, room for 1 wave/SIMD, nt", launch_np4<80, 5, 1, true, 1, 0, false, 4, 2, 0>},
-    {"caar_np4_kernel<80, 4, 1, true, true, 1, false, false, false>", "5 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<80, 4, 1, true, 1, 0, false, 4, 2, 0>},
+    {"caar_np4_kernel<80, 2, 1, true, 2, 1, false, false, false, 8>", "10 waves x 2 tiles, room for 1 wave/SIMD, hybrid cache policy", launch_np4<80, 2, 1, 2, 1, 0, false, 4, 2, 0>},
+    {"caar_np4_kernel<80, 2, 1, true, 1, 1, false, false, false, 8>", "10 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<80, 2, 1, true, 1, 0, false, 4, 2, 0>},
+    {"caar_np4_kernel<80, 4, 2, true, 1, 1, false, false, false, 8>", "5 waves x 4 tiles, room for 2 waves/SIMD, nt", launch_np4<80, 4, 2, true, 1, 0, false, 4, 2, 0>},
+    {"caar_np4_kernel<80, 5, 1, true, 1, 1, false, false, false, 8>", "4 waves x 5 tiles, room for 1 wave/SIMD, nt", launch_np4<80, 5, 1, true, 1, 0, false, 4, 2, 0>},
+    {"caar_np4_kernel<80, 4, 1, true, 1, 1, false, false, false, 8>", "5 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<80, 4, 1, true, 1, 0, false, 4, 2, 0>},
 };
 int kNp4Nlev80Count = sizeof(kNp4Nlev80) / sizeof(kNp4Nlev80[0]);
 KernelVariant kNp4Nlev96[] = {
-    {"caar_np4_kernel<96, 2, 1, true, true, 1, false, false, false>", "12 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<96, 2, 1, true, 1>},
-    {"caar_np4_kernel<96, 3, 1, true, true, 1, false, false, false>", "8 waves x 3 tiles, room for 1 wave/SIMD, nt", launch_np4<96, 3, 1, true, 1>},
-    {"caar_np4_kernel<96, 4, 2, true, true, 1, false, false, false>", "6 waves x 4 tiles, room for 2 waves/SIMD, nt", launch_np4<96, 4, 2, true, 1>},
-    {"caar_np4_kernel<96, 6, 1, true, true, 1, false, false, false>", "4 waves x 6 tiles, room for 1 wave/SIMD, nt", launch_np4<96, 6, 1, true, 1>},
-    {"caar_np4_kernel<96, 3, 2, true, true, 1, false, false, false>", "8 waves x 3 tiles, room for 2 waves/SIMD, nt", launch_np4<96, 3, 2, true, 1>},
+    {"caar_np4_kernel<96, 2, 1, true, 2, 1, false, false, false, 8>", "12 waves x 2 tiles, room for 1 wave/SIMD, hybrid cache policy", launch_np4<96, 2, 1, 2, 1>},
+    {"caar_np4_kernel<96, 2, 1, true, 1, 1, false, false, false, 8>", "12 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<96, 2, 1, true, 1>},
+    {"caar_np4_kernel<96, 3, 1, true, 1, 1, false, false, false, 8>", "8 waves x 3 tiles, room for 1 wave/SIMD, nt", launch_np4<96, 3, 1, true, 1>},
+    {"caar_np4_kernel<96, 4, 2, true, 1, 1, false, false, false, 8>", "6 waves x 4 tiles, room for 2 waves/SIMD, nt", launch_np4<96, 4, 2, true, 1>},
+    {"caar_np4_kernel<96, 6, 1, true, 1, 1, false, false, false, 8>", "4 waves x 6 tiles, room for 1 wave/SIMD, nt", launch_np4<96, 6, 1, true, 1>},
+    {"caar_np4_kernel<96, 3, 2, true, 1, 1, false, false, false, 8>", "8 waves x 3 tiles, room for 2 waves/SIMD, nt", launch_np4<96, 3, 2, true, 1>},
 };
 int kNp4Nlev96Count = sizeof(kNp4Nlev96) / sizeof(kNp4Nlev96[0]);
 // Any other level count up to 256: the kernel with a run-time level count (NLEV_T = 0).
@@ -548,8 +578,8 @@ static hipError_t launch_np4_dyn_shape(const KernelArgs& k, int num_elems, hipSt
     if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, true, true, VPF, false, false, true, MAXW>), dim3(grid), block, 0, stream, k);
     else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, false, true, VPF, false, false, true, MAXW>), dim3(grid), block, 0, stream, k);
   } else {
-    if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, true, true, PF, false, false, false, MAXW>), dim3(grid), block, 0, stream, k);
-    else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, false, true, PF, false, false, false, MAXW>), dim3(grid), block, 0, stream, k);
+    if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, true, 2, PF, false, false, false, MAXW>), dim3(grid), block, 0, stream, k);
+    else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, false, 2, PF, false, false, false, MAXW>), dim3(grid), block, 0, stream, k);
   }
   return hipGetLastError();
 }
@@ -563,18 +593,20 @@ KernelVariant kNp4NlevAny[] = {{"caar_np4_kernel<0, ...>", "run-time level count
 
 // level counts that are not a multiple of 4 (last tile partly empty)
 KernelVariant kNp4Nlev26[] = {
-    {"caar_np4_kernel<26, 7, 1, true, true, 1, false, false, false>", "1 waves x 7 tiles, room for 1 wave/SIMD, nt", launch_np4<26, 7, 1, true, 1>},
-    {"caar_np4_kernel<26, 1, 1, true, true, 1, false, false, false>", "7 waves x 1 tile, room for 1 wave/SIMD, nt", launch_np4<26, 1, 1, true, 1>},
-    {"caar_np4_kernel<26, 1, 3, true, true, 1, false, false, false>", "7 waves x 1 tile, room for 3 waves/SIMD, nt", launch_np4<26, 1, 3, true, 1>},
-    {"caar_np4_kernel<26, 1, 4, true, true, 1, false, false, false>", "7 waves x 1 tile, room for 4 waves/SIMD, nt", launch_np4<26, 1, 4, true, 1>},
+    {"caar_np4_kernel<26, 7, 1, true, 2, 1, false, false, false, 8>", "1 waves x 7 tiles, room for 1 wave/SIMD, hybrid cache policy", launch_np4<26, 7, 1, 2, 1>},
+    {"caar_np4_kernel<26, 7, 1, true, 1, 1, false, false, false, 8>", "1 waves x 7 tiles, room for 1 wave/SIMD, nt", launch_np4<26, 7, 1, true, 1>},
+    {"caar_np4_kernel<26, 1, 1, true, 1, 1, false, false, false, 8>", "7 waves x 1 tile, room for 1 wave/SIMD, nt", launch_np4<26, 1, 1, true, 1>},
+    {"caar_np4_kernel<26, 1, 3, true, 1, 1, false, false, false, 8>", "7 waves x 1 tile, room for 3 waves/SIMD, nt", launch_np4<26, 1, 3, true, 1>},
+    {"caar_np4_kernel<26, 1, 4, true, 1, 1, false, false, false, 8>", "7 waves x 1 tile, room for 4 waves/SIMD, nt", launch_np4<26, 1, 4, true, 1>},
 };
 int kNp4Nlev26Count = sizeof(kNp4Nlev26) / sizeof(kNp4Nlev26[0]);
 KernelVariant kNp4Nlev30[] = {
-    {"caar_np4_kernel<30, 2, 2, true, true, 1, false, false, false>", "4 waves x 2 tiles, room for 2 waves/SIMD, nt", launch_np4<30, 2, 2, true, 1>},
-    {"caar_np4_kernel<30, 2, 1, true, true, 1, false, false, false>", "4 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<30, 2, 1, true, 1>},
-    {"caar_np4_kernel<30, 1, 2, true, true, 1, false, false, false>", "8 waves x 1 tile, room for 2 waves/SIMD, nt", launch_np4<30, 1, 2, true, 1>},
-    {"caar_np4_kernel<30, 1, 4, true, true, 1, false, false, false>", "8 waves x 1 tile, room for 4 waves/SIMD, nt", launch_np4<30, 1, 4, true, 1>},
-    {"caar_np4_kernel<30, 4, 1, true, true, 1, false, false, false>", "2 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<30, 4, 1, true, 1>},
+    {"caar_np4_kernel<30, 2, 2, true, 2, 1, false, false, false, 8>", "4 waves x 2 tiles, room for 2 waves/SIMD, hybrid cache policy", launch_np4<30, 2, 2, 2, 1>},
+    {"caar_np4_kernel<30, 2, 2, true, 1, 1, false, false, false, 8>", "4 waves x 2 tiles, room for 2 waves/SIMD, nt", launch_np4<30, 2, 2, true, 1>},
+    {"caar_np4_kernel<30, 2, 1, true, 1, 1, false, false, false, 8>", "4 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<30, 2, 1, true, 1>},
+    {"caar_np4_kernel<30, 1, 2, true, 1, 1, false, false, false, 8>", "8 waves x 1 tile, room for 2 waves/SIMD, nt", launch_np4<30, 1, 2, true, 1>},
+    {"caar_np4_kernel<30, 1, 4, true, 1, 1, false, false, false, 8>", "8 waves x 1 tile, room for 4 waves/SIMD, nt", launch_np4<30, 1, 4, true, 1>},
+    {"caar_np4_kernel<30, 4, 1, true, 1, 1, false, false, false, 8>", "2 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<30, 4, 1, true, 1>},
 };
 int kNp4Nlev30Count = sizeof(kNp4Nlev30) / sizeof(kNp4Nlev30[0]);
 
