@@ -173,12 +173,13 @@ const char *caar_variant_info(int np, int nlev, int variant);
  * XCDs (all XCDs sweep the arrays together: measured 2-4 % faster, better DRAM locality);
  * 1 gives each XCD one contiguous eighth of the element range.  Same results either way. */
 int caar_set_xcd_chunked(int on);
-/* Hybrid cache policy of the default NP=4 kernels: bytes/(0.8*algorithmic bytes) elements, spread
- * evenly over every launch, are accessed with the default cache policy, the rest with non-temporal
- * (streaming) loads and stores, which do not allocate in the 256 MB memory-side Infinity Cache —
- * so a host that calls again on the same arrays finds those head elements there instead of in HBM.
- * Default 160 MiB (best of a sweep; beyond ~200 MiB the set no longer fits the cache and thrashes);
- * 0 makes every access streaming.  Same results either way.  Process-wide. */
+/* Hybrid cache policy of the default NP=4 kernels: all element data streams with non-temporal
+ * loads and stores, which do not allocate in the 256 MB memory-side Infinity Cache — except the
+ * three read-modify-write accumulators (derived_vn0, omega_p, eta_dot_dpdn) of `bytes` worth of
+ * elements, spread evenly over every launch, which use the default policy: a host that calls again
+ * on the same arrays finds them in the cache instead of in HBM (one read and one write saved per
+ * byte and call).  Default 192 MiB (best of a sweep); 0 makes every access streaming.  Same
+ * results either way.  Process-wide. */
 int caar_set_cache_window(long long bytes);
 
 /* ---- Fortran-layout ingest / egress -----------------------------------------------

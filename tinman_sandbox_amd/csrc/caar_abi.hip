@@ -129,7 +129,7 @@ struct HostConstants {
 
 static int g_xcd_chunked = 0;
 // bytes of element data the hybrid cache policy keeps in the memory-side cache (0: none, all streaming)
-static long long g_cache_window = 160LL << 20;  // best of a 0..384 MB sweep at NLEV 72 and 128 (256 MB cache, shared with everything else)  // workgroup -> element mapping, see element_of_block()
+static long long g_cache_window = 192LL << 20;  // best of a 0..320 MB sweep at NLEV 72 and 128 (the cache holds 256 MB, shared with everything else)  // workgroup -> element mapping, see element_of_block()
 
 struct CaarContext {
   CaarDims dims;
@@ -303,12 +303,13 @@ static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const Caar
   k.nelem = p->nete - p->nets;
   k.per_xcd = g_xcd_chunked ? (k.nelem + 7) / 8 : 0;
   {
-    // distinct bytes one element update touches: ~0.8 x the algorithmic bytes (read-modify-write blocks once)
-    const long long per_elem = caar_algorithmic_bytes(dims->np, dims->nlev, p->qn0 < 0) * 4 / 5;
+    // what the hybrid policy keeps per chosen element: vn0 (2 blocks), omega_p, eta_dot_dpdn
+    const long long pp = (long long)dims->np * dims->np;
+    const long long per_elem = 8 * (4 * pp * dims->nlev + pp);
     const long long n = per_elem > 0 ? g_cache_window / per_elem : 0;
     // that many elements, spread evenly over the launch so that in steady state a constant share of the
     // workgroups is served by the cache instead of HBM
-    k.cache_stride = n <= 0 ? 0 : (n >= k.nelem ? 1 : (int)((k.nelem + n - 1) / n));
+    k.cache_count = n <= 0 ? 0 : (n >= k.nelem ? k.nelem : (int)n);
   }
   k.n0 = p->n0;
   k.np1 = p->np1;

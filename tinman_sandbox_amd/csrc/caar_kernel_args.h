@@ -31,7 +31,8 @@ struct KernelArgs {
   int nets;           // first element of this launch
   int nelem;          // elements in this launch
   int per_xcd;        // 0: element = nets + blockIdx.x; else XCD-chunked mapping (element_of_block)
-  int cache_stride;   // hybrid cache policy: every cache_stride-th element of the launch uses the default policy (0: none)
+  int cache_count;    // hybrid cache policy: that many elements, spread evenly over the launch, keep their
+                      // accumulators in the memory-side cache (0: none)
   int n0, np1, nm1;
   int qn0;            // -1: dry
   int qsize_d, timelevels;
@@ -58,6 +59,13 @@ __device__ __forceinline__ long long element_of_block(const KernelArgs& k, unsig
   const unsigned x = b & 7u, s = b >> 3;
   const long long e = (long long)x * k.per_xcd + s;
   return (s < (unsigned)k.per_xcd && e < k.nelem) ? k.nets + e : -1;
+}
+
+// Hybrid cache policy: is element `rel` (0 .. nelem-1 inside the launch) one of the cache_count evenly
+// spread chosen ones?  (Bresenham: floor((rel+1)*c/n) > floor(rel*c/n).)
+__device__ __forceinline__ bool element_is_cached(const KernelArgs& k, long long rel) {
+  const unsigned long long c = (unsigned)k.cache_count, n = (unsigned)k.nelem;
+  return c != 0 && ((unsigned long long)(rel + 1) * c) / n > ((unsigned long long)rel * c) / n;
 }
 
 // 1/x for a normal, non-zero fp64 x: v_rcp_f64 seed + two Newton steps (5 instructions,

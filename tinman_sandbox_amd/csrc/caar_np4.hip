@@ -81,8 +81,10 @@ enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, 
 // RAGGED), LDS is sized for the largest count.  Serves every PLEV the reference can be
 // configured with (config.h.in:3) that has no kernel of its own.
 // DYNW: the most waves a workgroup of that form may have (its launch bound).
-// SNT: non-temporal (streaming) loads and stores.
-template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW>
+// SNT: non-temporal (streaming) loads and stores; ANT: the same for the three read-modify-write
+// accumulators (derived_vn0, omega_p, eta_dot_dpdn), which a hybrid-policy kernel keeps in the
+// memory-side cache for part of the elements.
+template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW>
 __device__ __forceinline__ void caar_np4_element(const KernelArgs& k) {
   constexpr int PP = 16;               // GLL points per level
   constexpr bool DYN = NLEV_T == 0;
@@ -221,10 +223,10 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k) {
       x.vnm1 = stream_load<SNT>(v_nm1 + off);
       x.Tnm1 = stream_load<SNT>(T_nm1 + off);
       x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
-      x.vn0 = stream_load<SNT>(vn0 + off);
-      x.om = stream_load<SNT>(omega_p + off);
+      x.vn0 = stream_load<ANT>(vn0 + off);
+      x.om = stream_load<ANT>(omega_p + off);
       x.pec = stream_load<SNT>(pecnd + off);
-      x.eta = stream_load<SNT>(eta + off);
+      x.eta = stream_load<ANT>(eta + off);
       return x;
     };
     // PF: when the update-phase inputs are requested: 2 = right behind the n0 loads,
@@ -405,18 +407,18 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k) {
       if (VADV) stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * (divdp[r] + eta_hi - eta_lo)));  // X:515-517
       else stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * divdp[r]));   // P:254
       stream_store<SNT>(phi_out + off, phi);                                        // P:294,303,309
-      stream_store<SNT>(omega_p + off, cur.om + k.eta_ave_w * om);                  // P:173
+      stream_store<ANT>(omega_p + off, cur.om + k.eta_ave_w * om);                  // P:173
       dbl2 vn;
       vn.x = cur.vn0.x + k.eta_ave_w * (u[r] * dp[r]);              // P:117
       vn.y = cur.vn0.y + k.eta_ave_w * (v[r] * dp[r]);              // P:118
-      stream_store<SNT>(vn0 + off, vn);
+      stream_store<ANT>(vn0 + off, vn);
       {
         const double e_new = cur.eta + (VADV ? k.eta_ave_w * eta_lo : eta_zero);  // P:172, X:271-272
         // ETA_COND: the update adds eta_ave_w * 0 (vertically Lagrangian), so the stored value
         // differs from the loaded one only for -0.0 or a non-finite eta_ave_w; storing only
         // then keeps the array bit-identical to the reference's and drops the write traffic.
         if (!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(cur.eta))
-          stream_store<SNT>(eta + off, e_new);
+          stream_store<ANT>(eta + off, e_new);
       }
       cur = nxt;
     }
@@ -435,22 +437,25 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k) {
 // The kernel.  POL = cache policy of the element arrays' loads and stores:
 //   1  non-temporal: every array is touched once per launch, nothing is worth keeping (+0.4..5 % over 0);
 //   0  the default policy;
-//   2  hybrid: every k.cache_stride-th element of the launch uses the default policy, the rest stream
-//      non-temporally.  The streaming traffic does not allocate in the memory-side Infinity Cache
-//      (256 MB), so what the chosen elements leave there survives the rest of the launch — and
-//      the next call on the same arrays (a time-stepping host, the reference's driver loop) finds
-//      them there: reads and the read-modify-write accumulators of ~1 000 elements never reach HBM.
-//      Both code paths live in the kernel; the choice is uniform per workgroup.
+//   2  hybrid: streaming like 1, except that for k.cache_count evenly spread elements the three
+//      read-modify-write accumulators (vn0, omega_p, eta_dot_dpdn: read AND written by every call, so
+//      a byte of them kept on chip saves two HBM transfers per call) use the default policy.
+//      Streaming traffic does not allocate in the memory-side Infinity Cache (256 MB), so those blocks
+//      survive the rest of the launch, and the next call on the same arrays (a time-stepping host, the
+//      reference's driver loop) finds them there instead of in HBM.  Both code paths live in the
+//      kernel; the choice is uniform per workgroup.
 template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, bool PERSIST, bool ETA_COND, bool VADV = false, int DYNW = 8>
 __global__ __launch_bounds__(NLEV_T ? (NLEV_T + 3) / 4 / TPW * 64 : DYNW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
   if constexpr (POL == 2) {
     static_assert(!PERSIST && !VADV, "hybrid cache policy: plain vertically-Lagrangian form only");
     const long long ie_s = element_of_block(k, blockIdx.x);
     if (ie_s < 0) return;
-    if (k.cache_stride > 0 && (unsigned)(ie_s - k.nets) % (unsigned)k.cache_stride == 0) caar_np4_element<NLEV_T, TPW, MINW, MOIST, false, PF, PERSIST, ETA_COND, VADV, DYNW>(k);
-    else caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, PF, PERSIST, ETA_COND, VADV, DYNW>(k);
+    if (element_is_cached(k, ie_s - k.nets))
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, false, PF, PERSIST, ETA_COND, VADV, DYNW>(k);
+    else
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, true, PF, PERSIST, ETA_COND, VADV, DYNW>(k);
   } else {
-    caar_np4_element<NLEV_T, TPW, MINW, MOIST, POL == 1, PF, PERSIST, ETA_COND, VADV, DYNW>(k);
+    caar_np4_element<NLEV_T, TPW, MINW, MOIST, POL == 1, POL == 1, PF, PERSIST, ETA_COND, VADV, DYNW>(k);
   }
 }
 
@@ -500,7 +505,7 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
-    {"caar_np4_kernel<72, 2, 1, true, 2, 1, false, false, false, 8>", "9 waves x 2 tiles, hybrid cache policy (every n-th element cached, bulk nt), update loads before the last barrier", launch_np4<72, 2, 1, 2, 1, 0, false, 3, 2, 0>},
+    {"caar_np4_kernel<72, 2, 1, true, 2, 1, false, false, false, 8>", "9 waves x 2 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<72, 2, 1, 2, 1, 0, false, 3, 2, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, false, false, 8>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, true, false, 8>", "9 waves x 2 tiles, nt; eta_dot_dpdn stored only where its bits change (skips the no-op write-back: NOT the contract traffic)", launch_np4<72, 2, 1, true, 1, 0, true, 3, 2, 0>},
     {"caar_np4_kernel<72, 3, 2, true, 1, 1, true, false, false, 8>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt", launch_np4<72, 3, 2, true, 1, 1>},
@@ -513,7 +518,7 @@ KernelVariant kNp4Nlev72[] = {
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
-    {"caar_np4_kernel<128, 4, 2, true, 2, 1, false, false, false, 8>", "8 waves x 4 tiles, hybrid cache policy (every n-th element cached, bulk nt), update loads before the last barrier", launch_np4<128, 4, 2, 2, 1, 0, false, 8, 1, 0>},
+    {"caar_np4_kernel<128, 4, 2, true, 2, 1, false, false, false, 8>", "8 waves x 4 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<128, 4, 2, 2, 1, 0, false, 8, 1, 0>},
     {"caar_np4_kernel<128, 4, 2, true, 1, 1, false, false, false, 8>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 1, 0>},
     {"caar_np4_kernel<128, 4, 2, true, 1, 0, false, false, false, 8>", "8 waves x 4 tiles, nt, update loads one tile ahead", launch_np4<128, 4, 2, true, 0>},
     {"caar_np4_kernel<128, 4, 2, true, 0, 1, false, false, false, 8>", "8 waves x 4 tiles, default cache policy", launch_np4<128, 4, 2, false, 1>},
