@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--nlev", type=int, default=72)
     ap.add_argument("--elems-per-gpu", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--isolated", action="store_true",
+                    help="also time 20 launches one by one (roofline.kernel_ms_isolated_*)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short extra measurements of BASELINE.json configs[3] and [4]")
     ap.add_argument("--cpu-seconds", type=float, default=1.5,
@@ -253,9 +255,11 @@ def main():
     # per-launch spread (median and min), outside the timed region: one event pair per
     # launch.  These intervals come out ~4 % shorter than the back-to-back average above: a launch
     # that starts on an idle chip does not share HBM with the write-back of its predecessor's
-    # dirty cache lines.  The headline and roofline.achieved use the back-to-back figure.
+    # dirty cache lines.  The headline and roofline.achieved use the back-to-back figure.  Opt-in
+    # (--isolated): these extra launches would otherwise shift the per-kernel average of a
+    # rocprofv3 --stats run of this command away from roofline.kernel_ms.
     per_launch = []
-    if rank == 0:
+    if rank == 0 and args.isolated:
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
         for a, b in evs:
             a.record(stream)
