@@ -287,3 +287,29 @@ def test_half_the_hbm_in_one_launch(oracle):
         a.elapsed_time(b), tsa.algorithmic_bytes(4, 72) * E / a.elapsed_time(b) / 1e6))
     del data
     torch.cuda.empty_cache()
+
+
+def test_cache_window_changes_nothing_but_speed():
+    """caar_set_cache_window: which elements keep their accumulators in the Infinity Cache is a
+    cache-policy choice; every setting must give bit-identical arrays."""
+    lib = tsa.library().lib
+    arrs = cases.hashed_arrays(4, 72, 37, seed=251)
+    Dvv = cases.dvv_for(4)
+    sc = po.default_scalars(72)
+    sc.update(qn0=1, dt2=0.5, nets=2, nete=35)
+    ref = None
+    try:
+        for window in (192 << 20, 0, 1 << 16, 300 * 1024, 1 << 40):
+            assert lib.caar_set_cache_window(window) == 0
+            data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+            tsa.compute_and_apply_rhs(data)
+            tsa.compute_and_apply_rhs(data)
+            torch.cuda.synchronize()
+            got = data.arrays.to_numpy()
+            if ref is None:
+                ref = got
+            for n in tsa.ARRAY_NAMES:
+                assert np.array_equal(got[n], ref[n]), (window, n)
+        assert lib.caar_set_cache_window(-1) != 0
+    finally:
+        lib.caar_set_cache_window(192 << 20)
