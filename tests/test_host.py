@@ -31,7 +31,16 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(m.CaarLibrary.SYMBOLS)
     for s in declared:
         assert hasattr(lib.lib, s), s
-    assert lib.lib.caar_abi_version() == 2
+    import __graft_entry__ as entry
+    assert lib.lib.caar_abi_version() == entry.header_abi_version()
+
+
+def test_graft_entry_build_succeeds_on_a_built_tree(capsys):
+    """The driver's official "does it build" entry point: compiles whatever is stale (nothing,
+    on a built tree), loads the library and checks it against include/caar.h."""
+    import __graft_entry__ as entry
+    entry.build()
+    assert "built" in capsys.readouterr().out
 
 
 def test_supported_variants_and_names(lib):
