@@ -108,6 +108,49 @@ def test_gll_matrix_reproduces_np4_literals(oracle):
     assert np.max(np.abs(D8.sum(axis=1))) < 1e-13
 
 
+def _independent_gll_nodes(np_):
+    """GLL nodes by a route neither generator uses: +-1 and the eigenvalue-based roots numpy finds
+    for the monomial-basis polynomial d/dx P_N (both generators run Newton on Legendre recurrences)."""
+    from numpy.polynomial import legendre as leg, polynomial as poly
+    N = np_ - 1
+    mono = leg.leg2poly([0.0] * N + [1.0])          # P_N in the monomial basis
+    inner = np.sort(np.real(poly.polyroots(poly.polyder(mono))))
+    return np.concatenate(([-1.0], inner, [1.0]))
+
+
+@pytest.mark.parametrize("np_", [4, 8])
+@pytest.mark.parametrize("which", ["oracle_c", "host_python"])
+def test_derivative_matrix_pinned_without_its_generator(oracle, np_, which):
+    """NP=8 has no reference literals (data_structures.cpp:152-162 hard-codes np=4),
+    and both sides of the NP=8 parity tests use this repo's matrix — so the matrix itself is pinned
+    by properties that DEFINE it, checked with nodes obtained independently of both generators:
+      * Dvv[i][j] = l_j'(x_i) (the reference's storage, Dvv[i][j] = values[j*np+i]): exact
+        differentiation of every monomial x^k, k = 0..np-1, at the GLL nodes;
+      * antisymmetry under the node reflection x -> -x: D[i][j] = -D[N-i][N-j];
+      * summation by parts with the GLL weights w_i = 2/(N(N+1)P_N(x_i)^2): W D + (W D)^T =
+        diag(-1, 0, .., 0, 1) — holds only on the true GLL nodes (quadrature exact to degree 2N-1);
+      * np=4: the same checks pass on the reference's literals, so the convention is the reference's."""
+    import tinman_sandbox_amd as tsa
+    D = oracle.dvv_gll(np_) if which == "oracle_c" else tsa.gll_derivative_matrix(np_)
+    N = np_ - 1
+    x = _independent_gll_nodes(np_)
+    for k in range(np_):
+        want = k * x ** (k - 1) if k > 0 else np.zeros(np_)
+        assert np.max(np.abs(D @ x ** k - want)) < 2e-13 * max(1, k * k), k
+    assert np.max(np.abs(D + D[::-1, ::-1])) < 1e-13
+    PN = np.polynomial.legendre.Legendre.basis(N)(x)
+    W = np.diag(2.0 / (N * (N + 1) * PN ** 2))
+    B = np.zeros((np_, np_))
+    B[0, 0], B[N, N] = -1.0, 1.0
+    assert np.max(np.abs(W @ D + (W @ D).T - B)) < 1e-13
+    if np_ == 4:  # the reference's own literals satisfy the same definitions
+        R = oracle.dvv_np4(False)
+        for k in range(4):
+            want = k * x ** (k - 1) if k > 0 else np.zeros(4)
+            assert np.max(np.abs(R @ x ** k - want)) < 1e-14
+        assert np.max(np.abs(R - D)) < 2e-15
+
+
 needs_ref = pytest.mark.skipif(not po.have_reference(4, 72),
                                reason="oracle/_ref not built (needs /root/reference)")
 
