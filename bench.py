@@ -5,10 +5,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one compute_and_apply_rhs call over every element resident on the GPU
-(BASELINE.json configs[1]: NP=4, NLEV=72, 10 000 elements per GPU, fp64, moist
-branch, the reference's closed-form synthetic arrays).  Elements shard
-embarrassingly: every rank owns a contiguous slab of the global element range and
-there is no data-path collective (weak scaling: 10 000 elements per GPU).
+(fp64, moist branch, the reference's closed-form synthetic arrays).  --gpus 1 is
+BASELINE.json configs[1]: NP=4, NLEV=72, 10 000 elements.  --gpus N > 1 holds 12 500
+elements per GPU, so --gpus 8 is configs[2] (100 000 elements sharded over 8 GPUs);
+the same 12 500-element launch is also measured at N=1 ("other_configs") so the two
+are comparable.  Elements shard embarrassingly: every rank owns a contiguous slab of
+the global element range and there is no data-path collective (weak scaling).
 
 Rank 0 prints ONE JSON line: metric/value (whole-job element updates per second),
 "roofline" for the dominant kernel (algorithmic bytes per launch / HIP-event
@@ -36,7 +38,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--np", type=int, default=4, dest="np_")
     ap.add_argument("--nlev", type=int, default=72)
-    ap.add_argument("--elems-per-gpu", type=int, default=10000)
+    ap.add_argument("--elems-per-gpu", type=int, default=None,
+                    help="elements resident per GPU (weak scaling). Default: 10 000 at --gpus 1 (BASELINE.json "
+                         "configs[1]); 12 500 at --gpus N > 1, so that --gpus 8 is configs[2] (100 000 elements "
+                         "sharded over 8 GPUs)")
+    ap.add_argument("--total-elems", type=int, default=None,
+                    help="total elements of the job, cut into contiguous slabs of ceil(E/N) (overrides "
+                         "--elems-per-gpu; the last rank may hold fewer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--isolated", action="store_true",
                     help="also time 20 launches one by one (roofline.kernel_ms_isolated_*)")
@@ -141,13 +149,9 @@ def measure_config(tsa, torch, dev, np_, nlev, elems, steps, warmup):
     gbs = balg * elems / (ms * 1e-3) / 1e9
     del data
     torch.cuda.empty_cache()
-    traffic = None
-    try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(
-            "np%d_nlev%d_e%d" % (np_, nlev, elems), {}).get("hbm_bytes_per_launch")
-    except Exception:
-        pass
+    traffic = static_traffic(np_, nlev, elems)
     return {"workload": "NP=%d NLEV=%d num_elems=%d" % (np_, nlev, elems), "kernel_ms": ms, "traffic": traffic,
+            "traffic_source": TRAFFIC_SOURCE,
             "element_updates_per_s": elems / (ms * 1e-3), "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
             "algorithmic_bytes_per_element": balg,
             "kernel": tsa.library().lib.caar_kernel_name(np_, nlev).decode()}
@@ -155,8 +159,10 @@ def measure_config(tsa, torch, dev, np_, nlev, elems, steps, warmup):
 
 def measured_ceilings(tsa, torch, dev, np_, nlev, elems):
     """What the memory system of THIS box delivers, next to the 8 TB/s spec peak (BASELINE.md
-    section 3): a plain 8 B/lane device copy, and the traffic skeleton — exactly the bytes and
-    addressing of the CAAR kernel with no arithmetic, non-temporal accesses."""
+    section 3): the tuned device copy (16 B/lane, several loads in flight, best variant on this
+    box; the guide's float4 copy reaches 6.29 TB/s), the naive 8 B/lane grid-stride copy that
+    calibrates the PMC counters, and the traffic skeleton — exactly the bytes and addressing of
+    the CAAR kernel with no arithmetic, non-temporal accesses."""
     import ctypes as C
     L = tsa.library()
     st = torch.cuda.current_stream(dev)
@@ -171,12 +177,22 @@ def measured_ceilings(tsa, torch, dev, np_, nlev, elems):
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) / reps * 1e-3
 
-    n = 1 << 27
+    n = 1 << 27  # 1 GiB in + 1 GiB out per copy: far beyond the 256 MiB Infinity Cache
     src = torch.ones(n, dtype=torch.float64, device=dev)
     dst = torch.empty_like(src)
-    t = timed(lambda: L.check(L.lib.caar_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n, 8,
-                                                     C.c_void_p(st.cuda_stream)), "copy"))
-    out = {"stream_copy_GBs": 2 * n * 8 / t / 1e9}
+    sp, dp, sv = C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_void_p(st.cuda_stream)
+    t = timed(lambda: L.check(L.lib.caar_stream_copy(dp, sp, n, 8, sv), "copy"))
+    out = {"stream_copy_naive_GBs": 2 * n * 8 / t / 1e9}
+    best = (0.0, -1)
+    per_variant = []
+    for v in range(L.lib.caar_stream_copy_tuned_variants()):
+        t = timed(lambda: L.check(L.lib.caar_stream_copy_tuned(dp, sp, n, v, sv), "tuned copy"))
+        gbs = 2 * n * 8 / t / 1e9
+        per_variant.append(round(gbs, 1))
+        best = max(best, (gbs, v))
+    out["stream_copy_GBs"] = best[0]
+    out["stream_copy_variant"] = L.lib.caar_stream_copy_tuned_info(best[1]).decode()
+    out["stream_copy_all_variants_GBs"] = per_variant
     del src, dst
     if np_ == 4:
         data = tsa.TestData().init_data(elems, np_, nlev, device=dev)
@@ -187,6 +203,33 @@ def measured_ceilings(tsa, torch, dev, np_, nlev, elems):
         del data
     torch.cuda.empty_cache()
     return out
+
+
+def static_traffic(np_, nlev, elems):
+    """HBM bytes per launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes, corrected as MI355X_MICROARCH.md prescribes).  NOT measured in this run: counters
+    need the profiler around the process."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        return j.get("np%d_nlev%d_e%d" % (np_, nlev, elems), {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+TRAFFIC_SOURCE = ("static: profiles/hbm_traffic.json (rocprofv3 --pmc passes committed with the repo; "
+                  "not measured in this run; L2-side counters: Infinity-Cache hits are counted as traffic)")
+
+
+def time_launches(tsa, torch, data, stream, dev, steps, warmup):
+    for _ in range(warmup):
+        tsa.compute_and_apply_rhs(data, stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(steps):
+        tsa.compute_and_apply_rhs(data, stream)
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / steps
 
 
 def main():
@@ -220,11 +263,17 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     reduce_dev = dev if backend == "nccl" else torch.device("cpu")
+    lib = tsa.library().lib
 
     # ---- this rank's slab of the global element range -------------------------------
-    total_elems = args.elems_per_gpu * world
+    if args.total_elems is not None:
+        total_elems = args.total_elems
+    else:
+        per_gpu = args.elems_per_gpu if args.elems_per_gpu is not None else (10000 if world == 1 else 12500)
+        total_elems = per_gpu * world
     nets, nete = tsa.shard_range(total_elems, rank, world)
-    data = tsa.TestData().init_data(nete - nets, args.np_, args.nlev, device=dev, first_elem=nets)
+    mine = nete - nets
+    data = tsa.TestData().init_data(mine, args.np_, args.nlev, device=dev, first_elem=nets)
     stream = torch.cuda.current_stream(dev)
 
     def barrier():
@@ -251,6 +300,19 @@ def main():
 
     from tinman_sandbox_amd import sharding
     wall_max, kernel_ms_max = sharding.max_over_ranks([wall, kernel_ms], dist, reduce_dev)
+    per_rank = sharding.gather_over_ranks([float(mine), kernel_ms], dist, reduce_dev)  # [[elems, ms], ...]
+
+    # The default NP=4 kernels keep the read-modify-write accumulators of part of the elements in the
+    # Infinity Cache between calls (caar_set_cache_window): bench.py replays the same arrays back to back,
+    # so those bytes are served on-chip and `achieved` above is ALGORITHMIC throughput, not DRAM
+    # throughput.  The same launches with every access streaming (window 0), outside the timed region:
+    kernel_ms_streaming = None
+    if args.np_ == 4:
+        window_default = lib.caar_get_cache_window()
+        lib.caar_set_cache_window(0)
+        kernel_ms_streaming = time_launches(tsa, torch, data, stream, dev, args.steps, 3)
+        lib.caar_set_cache_window(window_default)
+        (kernel_ms_streaming,) = sharding.max_over_ranks([kernel_ms_streaming], dist, reduce_dev)
 
     # per-launch spread (median and min), outside the timed region: one event pair per
     # launch.  These intervals come out ~4 % shorter than the back-to-back average above: a launch
@@ -270,17 +332,39 @@ def main():
 
     if rank == 0:
         balg = tsa.algorithmic_bytes(args.np_, args.nlev)
-        per_launch_bytes = balg * (nete - nets)
+        per_launch_bytes = balg * mine
         achieved = per_launch_bytes / (kernel_ms_max * 1e-3) / 1e9
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(prof):
-            try:
-                j = json.load(open(prof))
-                key = "np%d_nlev%d_e%d" % (args.np_, args.nlev, nete - nets)
-                traffic = j.get(key, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        window = int(lib.caar_get_cache_window())
+        roof = {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": static_traffic(args.np_, args.nlev, mine),
+            "traffic_source": TRAFFIC_SOURCE,
+            "algorithmic_bytes_per_element": balg,
+            "elements_per_launch": mine,
+            "kernel_ms": kernel_ms_max,
+            "cache_window_bytes": window if args.np_ == 4 else 0,
+            "achieved_note": "algorithmic bytes / kernel time with the default hybrid cache policy: the "
+                             "accumulators of part of the elements stay in the Infinity Cache between the "
+                             "back-to-back calls, so DRAM traffic is lower than the algorithmic bytes; "
+                             "achieved_all_streaming is the same launch with the window set to 0"
+                             if args.np_ == 4 and window else "every access streams from/to HBM",
+            "kernel_ms_isolated_min": per_launch[0] if per_launch else None,
+            "kernel_ms_isolated_median": per_launch[len(per_launch) // 2] if per_launch else None,
+        }
+        if kernel_ms_streaming is not None:
+            a0 = per_launch_bytes / (kernel_ms_streaming * 1e-3) / 1e9
+            roof["achieved_all_streaming"] = a0
+            roof["frac_all_streaming"] = a0 / HBM_PEAK_GBS
+            roof["kernel_ms_all_streaming"] = kernel_ms_streaming
+        if world > 1:
+            roof["per_gpu"] = [{"rank": r, "elements": int(e), "kernel_ms": ms,
+                                "achieved": balg * e / (ms * 1e-3) / 1e9,
+                                "frac": balg * e / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                               for r, (e, ms) in enumerate(per_rank)]
         out = {
             "metric": "element-RHS-updates/sec (node) + achieved HBM GB/s, NP=%d NLEV=%d fp64" % (args.np_, args.nlev),
             "value": total_elems * args.steps / wall_max,
@@ -296,35 +380,25 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "compute_and_apply_rhs NP=%d NLEV=%d num_elems=%d per GPU (%d total), moist, "
-                            "reference closed-form element arrays" % (args.np_, args.nlev, args.elems_per_gpu, total_elems),
+                            "reference closed-form element arrays" % (args.np_, args.nlev, mine, total_elems),
                 "parallelism": "element-sharded x%d, no collectives" % world,
-                "kernel": tsa.library().lib.caar_kernel_name(args.np_, args.nlev).decode(),
+                "kernel": lib.caar_kernel_name(args.np_, args.nlev).decode(),
             },
             "hbm_gbs_algorithmic_job": total_elems * args.steps * balg / wall_max / 1e9,
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_element": balg,
-                "elements_per_launch": nete - nets,
-                "kernel_ms": kernel_ms_max,
-                "kernel_ms_isolated_min": per_launch[0] if per_launch else None,
-                "kernel_ms_isolated_median": per_launch[len(per_launch) // 2] if per_launch else None,
-            },
+            "roofline": roof,
         }
         if world == 1 and not args.no_other_configs and (args.np_, args.nlev) == (4, 72):
-            # BASELINE.json configs[3] (NP=4 NLEV=128, one GPU's share of 100 000 elements) and
-            # configs[4] (NP=8, 20 000 elements), kernel-only, same run; the headline stays configs[1]
+            # kernel-only, same run; the headline stays configs[1]:
+            #  * 12 500 elements NP=4 NLEV=72 = one GPU's share of configs[2] (what --gpus 8 runs per GPU)
+            #  * configs[3] NP=4 NLEV=128, one GPU's share of 100 000 elements
+            #  * configs[4] NP=8, 20 000 elements
             del data
             torch.cuda.empty_cache()
-            out["other_configs"] = [measure_config(tsa, torch, dev, 4, 128, 12500, 20, 3),
+            out["other_configs"] = [measure_config(tsa, torch, dev, 4, 72, 12500, 20, 3),
+                                    measure_config(tsa, torch, dev, 4, 128, 12500, 20, 3),
                                     measure_config(tsa, torch, dev, 8, 72, 20000, 10, 2)]
         if world == 1 and not args.no_other_configs:
-            out["roofline"]["measured_on_this_box"] = measured_ceilings(tsa, torch, dev, args.np_, args.nlev,
-                                                                        args.elems_per_gpu)
+            roof["measured_on_this_box"] = measured_ceilings(tsa, torch, dev, args.np_, args.nlev, mine)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.np_, args.nlev, args.cpu_seconds)
         print(json.dumps(out))

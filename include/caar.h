@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAAR_ABI_VERSION 2
+#define CAAR_ABI_VERSION 3
 
 enum {
   CAAR_OK = 0,
@@ -165,9 +165,11 @@ int caar_launch_state_norms(const CaarDims *dims, const CaarArrays *dev, int tl,
 const char *caar_kernel_name(int np, int nlev);
 /* Tuning: each (np, nlev) is compiled in a few launch shapes (tiles per wavefront,
  * register budget => workgroups per CU).  Variant 0 is the default; all variants
- * compute the same thing.  Process-wide, not thread-safe against concurrent launches. */
+ * compute the same thing.  Process-wide; the selection is an atomic that every launch reads once, so
+ * selecting while other threads launch is safe (a launch uses the old or the new variant). */
 int caar_num_variants(int np, int nlev);
 int caar_select_variant(int np, int nlev, int variant);
+int caar_selected_variant(int np, int nlev);
 const char *caar_variant_info(int np, int nlev, int variant);
 /* Workgroup -> element mapping: 0 (default) deals consecutive elements round-robin over the
  * XCDs (all XCDs sweep the arrays together: measured 2-4 % faster, better DRAM locality);
@@ -179,8 +181,10 @@ int caar_set_xcd_chunked(int on);
  * elements, spread evenly over every launch, which use the default policy: a host that calls again
  * on the same arrays finds them in the cache instead of in HBM (one read and one write saved per
  * byte and call).  Default 192 MiB (best of a sweep); 0 makes every access streaming.  Same
- * results either way.  Process-wide. */
+ * results either way.  Process-wide, atomic, read once per launch (as the variant selection). */
+#define CAAR_CACHE_WINDOW_DEFAULT (192LL << 20)
 int caar_set_cache_window(long long bytes);
+long long caar_get_cache_window(void);
 
 /* ---- Fortran-layout ingest / egress -----------------------------------------------
  * A Fortran host holds the same 16 arrays with the FIRST index fastest
@@ -207,6 +211,15 @@ int caar_layout_to_f90(const CaarDims *dims, const CaarArrays *caar_dev, const C
  * (0 = the shape of the default kernel); unknown variants return hipErrorInvalidValue. */
 int caar_stream_copy(double *dst_dev, const double *src_dev, long long n_doubles, int lane_bytes,
                      void *stream);
+/* Tuned device copy of n_doubles (even; 16-byte aligned buffers): 16 bytes per lane, several
+ * independent loads in flight per lane, contiguous 1 KiB wave segments, grid = CUs x resident
+ * workgroups; `variant` in [0, caar_stream_copy_tuned_variants()) picks unroll / cache policy /
+ * grid size (caar_stream_copy_tuned_info: text).  The ceiling bench.py quotes next to the spec
+ * peak is the best of these on the box it runs on. */
+int caar_stream_copy_tuned(double *dst_dev, const double *src_dev, long long n_doubles, int variant,
+                           void *stream);
+int caar_stream_copy_tuned_variants(void);
+const char *caar_stream_copy_tuned_info(int variant);
 int caar_traffic_skeleton(const CaarDims *dims, const CaarArrays *dev, const CaarParams *params,
                           int variant, void *stream);
 

@@ -57,6 +57,10 @@ def _worker(rank, world, port, total_elems, out_dir):
         # timing reduction
         t = sharding.max_over_ranks([1.0 + rank, 5.0 - rank], dist)
         assert t == [float(world), 5.0]
+        # per-rank figures of bench.py's roofline.per_gpu, in rank order on every rank
+        g = sharding.gather_over_ranks([float(nete - nets), 0.25 * (rank + 1)], dist)
+        assert g == [[float(sharding.shard_range(total_elems, r, world)[1] - sharding.shard_range(total_elems, r, world)[0]),
+                      0.25 * (r + 1)] for r in range(world)]
         dist.barrier()
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     finally:
@@ -74,3 +78,4 @@ def test_single_process_paths():
     per = torch.tensor([[1.0, 4.0, 9.0], [3.0, 12.0, 16.0]])
     assert sharding.gather_slab_norms(per) == (2.0, 4.0, 5.0)
     assert sharding.max_over_ranks([1.5, 2.5]) == [1.5, 2.5]
+    assert sharding.gather_over_ranks([1.5, 2.5]) == [[1.5, 2.5]]

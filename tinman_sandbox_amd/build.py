@@ -32,13 +32,29 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def build_library(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
+def build_library(force=False, verbose=False, jobs=4):
+    """One object per .hip source (only stale ones are recompiled, `jobs` at a time), then one
+    link: editing one kernel file costs one compile, not seven."""
+    from concurrent.futures import ThreadPoolExecutor
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
         os.path.join(HERE, "..", "include", "caar.h")]
-    if force or _stale(LIB, deps):
-        cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-fno-gpu-rdc"] + srcs + ["-o", LIB]
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
+
+    def compile_one(name):
+        src, obj = os.path.join(CSRC, name), os.path.join(objdir, name.replace(".hip", ".o"))
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [hipcc()] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(compile_one, HIP_SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -61,7 +61,7 @@ class CaarLibrary:
     SYMBOLS = ("caar_supported", "caar_abi_version", "caar_device_count", "caar_strerror", "caar_array_len",
                "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator", "caar_sphere_operator_range", "caar_reciprocal",
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
-               "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_traffic_skeleton", "caar_create", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_download_f90",
+               "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_selected_variant", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_stream_copy_tuned", "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_create", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_download_f90",
                "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
                "caar_time_runs", "caar_run_steps", "caar_map_host", "caar_run_mapped", "caar_unmap_host")
 
@@ -98,11 +98,16 @@ class CaarLibrary:
         L.caar_variant_info.restype = C.c_char_p
         L.caar_set_xcd_chunked.argtypes = [C.c_int]
         L.caar_set_cache_window.argtypes = [C.c_longlong]
+        L.caar_get_cache_window.restype = C.c_longlong
+        L.caar_selected_variant.argtypes = [C.c_int, C.c_int]
         L.caar_layout_from_f90.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays),
                                            C.POINTER(_CaarArrays), C.c_int, C.c_int, vp]
         L.caar_layout_to_f90.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays),
                                          C.POINTER(_CaarArrays), C.c_int, C.c_int, C.c_int, vp]
         L.caar_stream_copy.argtypes = [vp, vp, C.c_longlong, C.c_int, vp]
+        L.caar_stream_copy_tuned.argtypes = [vp, vp, C.c_longlong, C.c_int, vp]
+        L.caar_stream_copy_tuned_info.argtypes = [C.c_int]
+        L.caar_stream_copy_tuned_info.restype = C.c_char_p
         L.caar_traffic_skeleton.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays),
                                             C.POINTER(_CaarParams), C.c_int, vp]
         L.caar_create.argtypes = [C.POINTER(vp), C.POINTER(_CaarDims), C.c_int]

@@ -5,8 +5,10 @@
 // requested dimensions exists the call fails with an error code.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -29,6 +31,9 @@ hipError_t launch_state_norms(const double* v, const double* T, const double* dp
 
 hipError_t launch_stream_copy(double* dst, const double* src, size_t n_doubles, int lane_bytes,
                               hipStream_t stream);
+hipError_t launch_stream_copy_tuned(double* dst, const double* src, size_t n_doubles, int variant, hipStream_t stream);
+int stream_copy_tuned_variants();
+const char* stream_copy_tuned_info(int v);
 hipError_t launch_sphere_operator(int np, int which, const double* in, double* out, const double* D,
                                   const double* Dinv, const double* metdet, const double* rmetdet,
                                   const double* dvv, int ie, int ne, int nlevels, double rrearth, hipStream_t s);
@@ -38,35 +43,30 @@ hipError_t launch_layout(double* dst, const double* src, size_t n, int np, int n
 hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t stream);
 hipError_t launch_traffic_skeleton_np8(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t stream);
 
+// `selected` is the only mutable member: atomic, read ONCE per launch (launch_choice), so a
+// caar_select_variant racing with launches on other threads is well defined (each launch uses
+// either the old or the new variant, never a mixture).
 struct Config {
   int np, nlev;
   const KernelVariant* variants;
   int count;
-  int selected;
+  std::atomic<int> selected;
 };
 static Config* configs(int* n) {
+  // built once, thread-safe (C++11 static initialisation); the counts are link-time constants of
+  // the kernel files
   static Config c[] = {
-      {4, 72, kNp4Nlev72, 0, 0},
-      {4, 128, kNp4Nlev128, 0, 0},
-      {8, 72, kNp8Nlev72, 0, 0},
-      {4, 32, kNp4Nlev32, 1, 0},
-      {4, 60, kNp4Nlev60, 1, 0},
-      {4, 64, kNp4Nlev64, 1, 0},
-      {4, 80, kNp4Nlev80, 1, 0},
-      {4, 96, kNp4Nlev96, 1, 0},
-      {4, 26, kNp4Nlev26, 1, 0},
-      {4, 30, kNp4Nlev30, 1, 0},
+      {4, 72, kNp4Nlev72, kNp4Nlev72Count, {0}},
+      {4, 128, kNp4Nlev128, kNp4Nlev128Count, {0}},
+      {8, 72, kNp8Nlev72, kNp8Nlev72Count, {0}},
+      {4, 32, kNp4Nlev32, kNp4Nlev32Count, {0}},
+      {4, 60, kNp4Nlev60, kNp4Nlev60Count, {0}},
+      {4, 64, kNp4Nlev64, kNp4Nlev64Count, {0}},
+      {4, 80, kNp4Nlev80, kNp4Nlev80Count, {0}},
+      {4, 96, kNp4Nlev96, kNp4Nlev96Count, {0}},
+      {4, 26, kNp4Nlev26, kNp4Nlev26Count, {0}},
+      {4, 30, kNp4Nlev30, kNp4Nlev30Count, {0}},
   };
-  c[0].count = kNp4Nlev72Count;
-  c[1].count = kNp4Nlev128Count;
-  c[2].count = kNp8Nlev72Count;
-  c[3].count = kNp4Nlev32Count;
-  c[4].count = kNp4Nlev60Count;
-  c[5].count = kNp4Nlev64Count;
-  c[6].count = kNp4Nlev80Count;
-  c[7].count = kNp4Nlev96Count;
-  c[8].count = kNp4Nlev26Count;
-  c[9].count = kNp4Nlev30Count;
   *n = (int)(sizeof(c) / sizeof(c[0]));
   return c;
 }
@@ -76,7 +76,7 @@ static Config* find_config(int np, int nlev) {
   for (int i = 0; i < n; ++i)
     if (c[i].np == np && c[i].nlev == nlev) return &c[i];
   // NP=4: any other level count runs the kernel compiled for a run-time count
-  static Config any = {4, 0, kNp4NlevAny, 1, 0};
+  static Config any = {4, 0, kNp4NlevAny, 1, {0}};
   if (np == 4 && nlev >= 2 && nlev <= 256) return &any;
   return nullptr;
 }
@@ -127,9 +127,28 @@ struct HostConstants {
 };
 }  // namespace caar
 
-static int g_xcd_chunked = 0;
-// bytes of element data the hybrid cache policy keeps in the memory-side cache (0: none, all streaming)
-static long long g_cache_window = 192LL << 20;  // best of a 0..320 MB sweep at NLEV 72 and 128 (the cache holds 256 MB, shared with everything else)  // workgroup -> element mapping, see element_of_block()
+// Process-wide tuning knobs.  Atomics, read once per launch into a LaunchChoice, so setters may race
+// with launches on other threads (HOMME's horizontal OpenMP calls the routine from several host
+// threads): every launch sees one consistent set of values.
+static std::atomic<int> g_xcd_chunked{0};  // workgroup -> element mapping, see element_of_block()
+// bytes of element data the hybrid cache policy keeps in the memory-side cache (0: none, all streaming);
+// default = best of a 0..320 MB sweep at NLEV 72 and 128 (the cache holds 256 MB, shared with everything else)
+static std::atomic<long long> g_cache_window{CAAR_CACHE_WINDOW_DEFAULT};
+
+namespace caar {
+struct LaunchChoice {
+  int variant;
+  int xcd_chunked;
+  long long cache_window;
+};
+static LaunchChoice launch_choice(const Config* cfg) {
+  LaunchChoice c;
+  c.variant = cfg ? cfg->selected.load(std::memory_order_relaxed) : 0;
+  c.xcd_chunked = g_xcd_chunked.load(std::memory_order_relaxed);
+  c.cache_window = g_cache_window.load(std::memory_order_relaxed);
+  return c;
+}
+}  // namespace caar
 
 struct CaarContext {
   CaarDims dims;
@@ -142,6 +161,7 @@ struct CaarContext {
   // caar_run_steps: the captured graph and what it was captured for
   hipGraphExec_t steps_exec;
   CaarParams steps_params;
+  caar::LaunchChoice steps_choice;  // variant / mapping / cache window baked into the captured launches
   int steps_n, steps_rotate;
   double steps_dvv[64];
   std::vector<double>* steps_hybi;
@@ -174,7 +194,7 @@ int caar_supported(int np, int nlev) { return caar::find_config(np, nlev) != nul
 
 const char* caar_kernel_name(int np, int nlev) {
   const caar::Config* c = caar::find_config(np, nlev);
-  return c ? c->variants[c->selected].kernel : nullptr;
+  return c ? c->variants[c->selected.load()].kernel : nullptr;
 }
 
 int caar_num_variants(int np, int nlev) {
@@ -186,18 +206,25 @@ int caar_select_variant(int np, int nlev, int variant) {
   caar::Config* c = caar::find_config(np, nlev);
   if (!c) return CAAR_EUNSUPPORTED;
   if (variant < 0 || variant >= c->count) return CAAR_EINVAL;
-  c->selected = variant;
+  c->selected.store(variant);
   return CAAR_OK;
+}
+
+int caar_selected_variant(int np, int nlev) {
+  const caar::Config* c = caar::find_config(np, nlev);
+  return c ? c->selected.load() : CAAR_EUNSUPPORTED;
 }
 
 int caar_set_cache_window(long long bytes) {
   if (bytes < 0) return CAAR_EINVAL;
-  g_cache_window = bytes;
+  g_cache_window.store(bytes);
   return CAAR_OK;
 }
 
+long long caar_get_cache_window(void) { return g_cache_window.load(); }
+
 int caar_set_xcd_chunked(int on) {
-  g_xcd_chunked = on ? 1 : 0;
+  g_xcd_chunked.store(on ? 1 : 0);
   return CAAR_OK;
 }
 
@@ -250,14 +277,20 @@ static int check_common(const CaarDims* d, const CaarParams* p) {
 }
 
 static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const CaarArrays* dev,
-                           const double* dvv_dev, const CaarParams* p);
-static void fill_args(caar::KernelArgs* k, const CaarDims* dims, const CaarArrays* dev,
-                      const double* dvv_dev, const CaarParams* p) {
-  fill_args_impl(*k, dims, dev, dvv_dev, p);
-}
+                           const double* dvv_dev, const CaarParams* p, const caar::LaunchChoice& ch);
+
+static int launch_with(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev, const CaarParams* p,
+                       void* stream, const caar::LaunchChoice* forced);
 
 int caar_launch(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev,
                 const CaarParams* p, void* stream) {
+  return launch_with(dims, dev, dvv_dev, p, stream, nullptr);
+}
+
+// forced != nullptr: the tuning knobs the caller already read (a graph capture bakes ONE choice into all of
+// its launches and into its cache key)
+static int launch_with(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev, const CaarParams* p,
+                       void* stream, const caar::LaunchChoice* forced) {
   int rc = check_common(dims, p);
   if (rc) return rc;
   if (!dev || !dvv_dev) return CAAR_EINVAL;
@@ -273,13 +306,14 @@ int caar_launch(const CaarDims* dims, const CaarArrays* dev, const double* dvv_d
   const int n = p->nete - p->nets;
   if (n == 0) return CAAR_OK;
 
+  const caar::LaunchChoice ch = forced ? *forced : caar::launch_choice(cfg);  // the knobs, read once
   caar::KernelArgs k;
-  fill_args(&k, dims, dev, dvv_dev, p);
-  return (int)cfg->variants[cfg->selected].launch(k, n, (hipStream_t)stream);
+  fill_args_impl(k, dims, dev, dvv_dev, p, ch);
+  return (int)cfg->variants[ch.variant].launch(k, n, (hipStream_t)stream);
 }
 
 static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const CaarArrays* dev,
-                           const double* dvv_dev, const CaarParams* p) {
+                           const double* dvv_dev, const CaarParams* p, const caar::LaunchChoice& ch) {
   k.D = dev->elem_D;
   k.Dinv = dev->elem_Dinv;
   k.fcor = dev->elem_fcor;
@@ -301,12 +335,12 @@ static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const Caar
   k.vadv = p->rsplit == 0 ? 1 : 0;
   k.nets = p->nets;
   k.nelem = p->nete - p->nets;
-  k.per_xcd = g_xcd_chunked ? (k.nelem + 7) / 8 : 0;
+  k.per_xcd = ch.xcd_chunked ? (k.nelem + 7) / 8 : 0;
   {
     // what the hybrid policy keeps per chosen element: vn0 (2 blocks), omega_p, eta_dot_dpdn
     const long long pp = (long long)dims->np * dims->np;
     const long long per_elem = 8 * (4 * pp * dims->nlev + pp);
-    const long long n = per_elem > 0 ? g_cache_window / per_elem : 0;
+    const long long n = per_elem > 0 ? ch.cache_window / per_elem : 0;
     // that many elements, spread evenly over the launch so that in steady state a constant share of the
     // workgroups is served by the cache instead of HBM
     k.cache_count = n <= 0 ? 0 : (n >= k.nelem ? k.nelem : (int)n);
@@ -333,6 +367,7 @@ int caar_sphere_operator(const CaarDims* dims, const CaarArrays* dev, const doub
   if (ie < 0 || ie >= dims->num_elems) return CAAR_EINVAL;
   if (dims->np != 4 && dims->np != 8) return CAAR_EUNSUPPORTED;
   if (!dev->elem_D || !dev->elem_Dinv || !dev->elem_metdet || !dev->elem_rmetdet) return CAAR_EINVAL;
+  if ((((size_t)in_dev) | ((size_t)out_dev)) & 15) return CAAR_EINVAL;  // vector fields move as 16-byte (u, v) pairs
   return (int)caar::launch_sphere_operator(dims->np, which, in_dev, out_dev, dev->elem_D, dev->elem_Dinv,
                                            dev->elem_metdet, dev->elem_rmetdet, dvv_dev, ie, 1, nlevels, rrearth,
                                            (hipStream_t)stream);
@@ -345,6 +380,7 @@ int caar_sphere_operator_range(const CaarDims* dims, const CaarArrays* dev, cons
   if (e0 < 0 || e1 > dims->num_elems || e0 > e1) return CAAR_EINVAL;
   if (dims->np != 4 && dims->np != 8) return CAAR_EUNSUPPORTED;
   if (!dev->elem_D || !dev->elem_Dinv || !dev->elem_metdet || !dev->elem_rmetdet) return CAAR_EINVAL;
+  if ((((size_t)in_dev) | ((size_t)out_dev)) & 15) return CAAR_EINVAL;
   return (int)caar::launch_sphere_operator(dims->np, which, in_dev, out_dev, dev->elem_D, dev->elem_Dinv,
                                            dev->elem_metdet, dev->elem_rmetdet, dvv_dev, e0, e1 - e0, nlevels,
                                            rrearth, (hipStream_t)stream);
@@ -396,6 +432,17 @@ int caar_stream_copy(double* dst_dev, const double* src_dev, long long n_doubles
   return (int)caar::launch_stream_copy(dst_dev, src_dev, (size_t)n_doubles, lane_bytes, (hipStream_t)stream);
 }
 
+int caar_stream_copy_tuned(double* dst_dev, const double* src_dev, long long n_doubles, int variant, void* stream) {
+  if (!dst_dev || !src_dev || n_doubles <= 0 || (n_doubles & 1)) return CAAR_EINVAL;
+  if ((((size_t)dst_dev) | ((size_t)src_dev)) & 15) return CAAR_EINVAL;
+  if (variant < 0 || variant >= caar::stream_copy_tuned_variants()) return CAAR_EINVAL;
+  return (int)caar::launch_stream_copy_tuned(dst_dev, src_dev, (size_t)n_doubles, variant, (hipStream_t)stream);
+}
+
+int caar_stream_copy_tuned_variants(void) { return caar::stream_copy_tuned_variants(); }
+
+const char* caar_stream_copy_tuned_info(int variant) { return caar::stream_copy_tuned_info(variant); }
+
 int caar_traffic_skeleton(const CaarDims* dims, const CaarArrays* dev, const CaarParams* p, int variant,
                           void* stream) {
   int rc = check_common(dims, p);
@@ -405,7 +452,7 @@ int caar_traffic_skeleton(const CaarDims* dims, const CaarArrays* dev, const Caa
     if (!*array_slot(dev, i)) return CAAR_EINVAL;
   if (p->nete == p->nets) return CAAR_OK;
   caar::KernelArgs k;
-  fill_args_impl(k, dims, dev, nullptr, p);
+  fill_args_impl(k, dims, dev, nullptr, p, caar::launch_choice(nullptr));
   if (dims->np == 8)
     return (int)caar::launch_traffic_skeleton_np8(k, dims->nlev, variant, p->nete - p->nets, (hipStream_t)stream);
   return (int)caar::launch_traffic_skeleton(k, dims->nlev, variant, p->nete - p->nets, (hipStream_t)stream);
@@ -563,14 +610,22 @@ int caar_run_steps(CaarContext* c, const CaarParams* p, int nsteps, int rotate) 
   const size_t nd = sizeof(double) * c->dims.np * c->dims.np, nh = (size_t)c->dims.nlev + 1;
   // the cached graph is valid for the same scalars AND the same Dvv / hybi VALUES (they are
   // baked into device buffers the kernels read, so only their content matters)
+  // ... and for the same variant / element mapping / cache window, which fill_args bakes into the
+  // captured kernel arguments (a knob changed after the capture must not replay the old launches)
+  const caar::LaunchChoice now = caar::launch_choice(caar::find_config(c->dims.np, c->dims.nlev));
   bool same = c->steps_exec && c->steps_n == nsteps && c->steps_rotate == (rotate != 0) &&
-              std::memcmp(c->steps_dvv, p->Dvv, nd) == 0;
+              c->steps_choice.variant == now.variant && c->steps_choice.xcd_chunked == now.xcd_chunked &&
+              c->steps_choice.cache_window == now.cache_window && std::memcmp(c->steps_dvv, p->Dvv, nd) == 0;
   if (same) {
-    CaarParams a = c->steps_params, b = *p;
-    a.Dvv = b.Dvv = nullptr;
-    a.hybi = b.hybi = nullptr;
-    a.hybi_dev = b.hybi_dev = nullptr;
-    same = std::memcmp(&a, &b, sizeof(a)) == 0;
+    // field by field: the struct has padding bytes a caller need not have initialised
+    const CaarParams &a = c->steps_params, &b = *p;
+    same = a.nets == b.nets && a.nete == b.nete && a.n0 == b.n0 && a.np1 == b.np1 && a.nm1 == b.nm1 &&
+           a.qn0 == b.qn0 && a.rsplit == b.rsplit &&
+           std::memcmp(&a.dt2, &b.dt2, sizeof(double)) == 0 && std::memcmp(&a.rrearth, &b.rrearth, sizeof(double)) == 0 &&
+           std::memcmp(&a.eta_ave_w, &b.eta_ave_w, sizeof(double)) == 0 &&
+           std::memcmp(&a.Rwater_vapor, &b.Rwater_vapor, sizeof(double)) == 0 &&
+           std::memcmp(&a.Rgas, &b.Rgas, sizeof(double)) == 0 && std::memcmp(&a.kappa, &b.kappa, sizeof(double)) == 0 &&
+           std::memcmp(&a.ps0, &b.ps0, sizeof(double)) == 0 && std::memcmp(&a.hyai0, &b.hyai0, sizeof(double)) == 0;
   }
   if (same && p->rsplit == 0)
     same = c->steps_hybi && std::memcmp(c->steps_hybi->data(), p->hybi, sizeof(double) * nh) == 0;
@@ -584,7 +639,7 @@ int caar_run_steps(CaarContext* c, const CaarParams* p, int nsteps, int rotate) 
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     for (int i = 0; i < nsteps && rc == CAAR_OK; ++i) {
-      rc = caar_launch(&c->dims, &c->dev, dvv_dev, &q, c->stream);
+      rc = launch_with(&c->dims, &c->dev, dvv_dev, &q, c->stream, &now);
       if (rotate) {  // data_structures.cpp:174-180
         const int t = q.np1;
         q.np1 = q.nm1;
@@ -605,6 +660,7 @@ int caar_run_steps(CaarContext* c, const CaarParams* p, int nsteps, int rotate) 
       return (int)e;
     }
     c->steps_params = *p;
+    c->steps_choice = now;
     c->steps_n = nsteps;
     c->steps_rotate = rotate != 0;
     std::memcpy(c->steps_dvv, p->Dvv, nd);
@@ -678,6 +734,7 @@ struct CaarHostMapping {
   bool registered[CAAR_NUM_ARRAYS];
   CaarArrays dev;        // the same memory as the device addresses it
   caar::HostConstants consts;
+  std::mutex* lock;      // caar_run_mapped from several host threads (disjoint [nets, nete)): SURVEY 8b
 };
 
 int caar_unmap_host(CaarHostMapping* m) {
@@ -692,6 +749,7 @@ int caar_unmap_host(CaarHostMapping* m) {
     }
   m->consts.destroy();
   if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m->lock;
   delete m;
   return rc;
 }
@@ -712,6 +770,11 @@ int caar_map_host(CaarHostMapping** out, const CaarDims* dims, const CaarArrays*
   m->dims = *dims;
   m->device = device;
   m->host = *host;
+  m->lock = new (std::nothrow) std::mutex();
+  if (!m->lock) {
+    delete m;
+    return CAAR_ENOMEM;
+  }
   hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
   for (int i = 0; e == hipSuccess && i < CAAR_NUM_ARRAYS; ++i) {
     double* h = *array_slot(host, i);
@@ -737,12 +800,22 @@ int caar_run_mapped(CaarHostMapping* m, const CaarParams* p) {
   HIP_TRY(hipSetDevice(m->device));
   if (p->rsplit == 0 && !p->hybi) return CAAR_EINVAL;
   CaarParams q = *p;
-  const double* dvv_dev = nullptr;
-  HIP_TRY(m->consts.sync(m->dims, &q, m->stream, &dvv_dev));
-  int rc = caar_launch(&m->dims, &m->dev, dvv_dev, &q, m->stream);
-  if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(m->stream));
-  return CAAR_OK;
+  hipEvent_t done = nullptr;
+  HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+  int rc;
+  {
+    // Re-entrant like the reference (disjoint [nets, nete) from several host threads with their own
+    // Control copies): the constants cache and the enqueue are serialised, the wait is not — each caller
+    // waits for its own launch only.
+    std::lock_guard<std::mutex> g(*m->lock);
+    const double* dvv_dev = nullptr;
+    rc = (int)m->consts.sync(m->dims, &q, m->stream, &dvv_dev);
+    if (rc == CAAR_OK) rc = caar_launch(&m->dims, &m->dev, dvv_dev, &q, m->stream);
+    if (rc == CAAR_OK) rc = (int)hipEventRecord(done, m->stream);
+  }
+  if (rc == CAAR_OK) rc = (int)hipEventSynchronize(done);
+  (void)hipEventDestroy(done);
+  return rc;
 }
 
 }  // extern "C"

@@ -33,6 +33,75 @@ hipError_t launch_stream_copy(double* dst, const double* src, size_t n_doubles, 
   return hipGetLastError();
 }
 
+// Tuned device copy: the ceiling to quote next to the 8 TB/s spec peak (MI355X_MICROARCH.md: a float4
+// copy reaches 6.29 TB/s = 79 %).  16 bytes per lane, UNROLL independent loads in flight per lane
+// before the first store, a workgroup owns contiguous chunks of 256*UNROLL*16 bytes (each wave
+// instruction is one 1 KiB segment), grid = CUs x WG_PER_CU resident workgroups walking the buffer
+// chunk-strided, optional non-temporal policy.  The plain grid-stride kernel above (one 8-byte
+// access in flight per lane and iteration) stays as the calibration run of the PMC counters.
+typedef double v2d __attribute__((ext_vector_type(2)));
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void stream_copy_tuned_kernel(v2d* __restrict__ dst, const v2d* __restrict__ src,
+                                                                size_t n16) {
+  constexpr size_t CHUNK = 256 * UNROLL;
+  const size_t nchunks = n16 / CHUNK;
+  for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const v2d* s = src + c * CHUNK + threadIdx.x;
+    v2d* d = dst + c * CHUNK + threadIdx.x;
+    v2d x[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) x[u] = NT ? __builtin_nontemporal_load(s + u * 256) : s[u * 256];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if (NT) __builtin_nontemporal_store(x[u], d + u * 256);
+      else d[u * 256] = x[u];
+    }
+  }
+  // tail (less than one chunk): first workgroup, one access per lane and iteration
+  if (blockIdx.x == 0)
+    for (size_t i = nchunks * CHUNK + threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+}
+
+struct CopyVariant {
+  const char* what;
+  int unroll, nt, wg_per_cu;
+};
+static const CopyVariant kCopyVariants[] = {
+    {"16 B/lane, 4 loads in flight, nt, 8 workgroups/CU", 4, 1, 8},
+    {"16 B/lane, 8 loads in flight, nt, 8 workgroups/CU", 8, 1, 8},
+    {"16 B/lane, 4 loads in flight, nt, 4 workgroups/CU", 4, 1, 4},
+    {"16 B/lane, 8 loads in flight, nt, 4 workgroups/CU", 8, 1, 4},
+    {"16 B/lane, 4 loads in flight, default policy, 8 workgroups/CU", 4, 0, 8},
+    {"16 B/lane, 8 loads in flight, default policy, 8 workgroups/CU", 8, 0, 8},
+    {"16 B/lane, 4 loads in flight, default policy, 4 workgroups/CU", 4, 0, 4},
+    {"16 B/lane, 2 loads in flight, nt, 8 workgroups/CU", 2, 1, 8},
+    {"16 B/lane, 2 loads in flight, default policy, 8 workgroups/CU", 2, 0, 8},
+    {"16 B/lane, 4 loads in flight, nt, 16 workgroups/CU (grid oversubscribed 2x)", 4, 1, 16},
+};
+int stream_copy_tuned_variants() { return (int)(sizeof(kCopyVariants) / sizeof(kCopyVariants[0])); }
+const char* stream_copy_tuned_info(int v) {
+  return (v >= 0 && v < stream_copy_tuned_variants()) ? kCopyVariants[v].what : nullptr;
+}
+
+hipError_t launch_stream_copy_tuned(double* dst, const double* src, size_t n_doubles, int variant, hipStream_t stream) {
+  if (variant < 0 || variant >= stream_copy_tuned_variants() || (n_doubles & 1)) return hipErrorInvalidValue;
+  const CopyVariant& cv = kCopyVariants[variant];
+  int dev = 0, cus = 256;
+  hipDeviceProp_t p;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+    cus = p.multiProcessorCount;
+  const dim3 grid(cus * cv.wg_per_cu), block(256);
+  v2d* d = reinterpret_cast<v2d*>(dst);
+  const v2d* s = reinterpret_cast<const v2d*>(src);
+  const size_t n16 = n_doubles / 2;
+#define CAAR_COPY(U, N) hipLaunchKernelGGL((stream_copy_tuned_kernel<U, N>), grid, block, 0, stream, d, s, n16)
+  if (cv.unroll == 2) { if (cv.nt) CAAR_COPY(2, true); else CAAR_COPY(2, false); }
+  else if (cv.unroll == 4) { if (cv.nt) CAAR_COPY(4, true); else CAAR_COPY(4, false); }
+  else { if (cv.nt) CAAR_COPY(8, true); else CAAR_COPY(8, false); }
+#undef CAAR_COPY
+  return hipGetLastError();
+}
+
 // cache-policy codes: 0 default, 1 nt (non-temporal), 2 sc1 (agent-scope: bypasses the L1 on
 // loads, drops the L2 line on stores; MI355X_MICROARCH.md "stores of each flavour")
 template <int POL, typename T>

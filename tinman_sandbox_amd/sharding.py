@@ -21,6 +21,16 @@ def max_over_ranks(values, dist=None, device="cpu"):
     return t.tolist()
 
 
+def gather_over_ranks(values, dist=None, device="cpu"):
+    """Every rank's list of floats, in rank order: [[rank 0's values], [rank 1's], ...]."""
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, t)
+        return [p.tolist() for p in parts]
+    return [t.tolist()]
+
+
 def gather_slab_norms(per_element_sq, dist=None, device="cpu"):
     """print_results_2norm over a sharded element range.
 
