@@ -77,6 +77,12 @@ static const CopyVariant kCopyVariants[] = {
     {"16 B/lane, 2 loads in flight, nt, 8 workgroups/CU", 2, 1, 8},
     {"16 B/lane, 2 loads in flight, default policy, 8 workgroups/CU", 2, 0, 8},
     {"16 B/lane, 4 loads in flight, nt, 16 workgroups/CU (grid oversubscribed 2x)", 4, 1, 16},
+    {"16 B/lane, 4 loads in flight, nt, 32 workgroups/CU (grid oversubscribed 4x)", 4, 1, 32},
+    {"16 B/lane, 4 loads in flight, nt, one 16 KiB chunk per workgroup", 4, 1, 0},
+    {"16 B/lane, 2 loads in flight, nt, one 8 KiB chunk per workgroup", 2, 1, 0},
+    {"16 B/lane, 2 loads in flight, nt, 32 workgroups/CU", 2, 1, 32},
+    {"16 B/lane, 4 loads in flight, default policy, one 16 KiB chunk per workgroup", 4, 0, 0},
+    {"16 B/lane, 1 load in flight, nt, one 4 KiB chunk per workgroup", 1, 1, 0},
 };
 int stream_copy_tuned_variants() { return (int)(sizeof(kCopyVariants) / sizeof(kCopyVariants[0])); }
 const char* stream_copy_tuned_info(int v) {
@@ -90,12 +96,19 @@ hipError_t launch_stream_copy_tuned(double* dst, const double* src, size_t n_dou
   hipDeviceProp_t p;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
     cus = p.multiProcessorCount;
-  const dim3 grid(cus * cv.wg_per_cu), block(256);
+  const size_t n16 = n_doubles / 2;
+  size_t nblocks = (size_t)cus * cv.wg_per_cu;
+  if (cv.wg_per_cu == 0) {  // one chunk per workgroup: the hardware dispatcher walks the buffer
+    nblocks = n16 / (256 * (size_t)cv.unroll);
+    if (nblocks == 0) nblocks = 1;
+    if (nblocks > 0x7fffffff) return hipErrorInvalidValue;
+  }
+  const dim3 grid((unsigned)nblocks), block(256);
   v2d* d = reinterpret_cast<v2d*>(dst);
   const v2d* s = reinterpret_cast<const v2d*>(src);
-  const size_t n16 = n_doubles / 2;
 #define CAAR_COPY(U, N) hipLaunchKernelGGL((stream_copy_tuned_kernel<U, N>), grid, block, 0, stream, d, s, n16)
-  if (cv.unroll == 2) { if (cv.nt) CAAR_COPY(2, true); else CAAR_COPY(2, false); }
+  if (cv.unroll == 1) { if (cv.nt) CAAR_COPY(1, true); else CAAR_COPY(1, false); }
+  else if (cv.unroll == 2) { if (cv.nt) CAAR_COPY(2, true); else CAAR_COPY(2, false); }
   else if (cv.unroll == 4) { if (cv.nt) CAAR_COPY(4, true); else CAAR_COPY(4, false); }
   else { if (cv.nt) CAAR_COPY(8, true); else CAAR_COPY(8, false); }
 #undef CAAR_COPY
@@ -135,13 +148,19 @@ __device__ __forceinline__ double2 ld2(const double2* p, bool) { return *p; }
 // NTL / NTS: cache policy of the loads / stores (0 default, 1 nt, 2 sc1); ALL_FIRST: issue every load of the element
 // before the first store (maximum bytes in flight) instead of tile by tile.
 // PP = 16: NP=4 (a 64-lane tile = 4 levels); PP = 64: NP=8 (a tile = one level).
-template <int NLEV, int TPW, int NTL, int NTS, bool ALL_FIRST, int PP = 16>
-__global__ __launch_bounds__(NLEV * PP / 64 / TPW * 64) void traffic_skeleton_np4(const KernelArgs k) {
+// WGW > 0: the element's waves are spread over workgroups of WGW waves (the skeleton has no cross-level
+// dependency): many small, short-lived workgroups per CU instead of one fat one — probes what the launch
+// shape alone costs.
+template <int NLEV, int TPW, int NTL, int NTS, bool ALL_FIRST, int PP = 16, int WGW = 0>
+__global__ __launch_bounds__((WGW ? WGW : NLEV * PP / 64 / TPW) * 64) void traffic_skeleton_np4(const KernelArgs k) {
   constexpr int BLK = NLEV * PP;
+  constexpr int WAVES = NLEV * PP / 64 / TPW;            // waves per element
+  constexpr int WG_PER_ELEM = WGW ? WAVES / WGW : 1;
+  static_assert(!WGW || WAVES % WGW == 0, "wave split");
   const int tid = threadIdx.x, lane = tid & 63, pt = lane & (PP - 1);
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6) + (WGW ? (int)(blockIdx.x % WG_PER_ELEM) * WGW : 0);
   const unsigned ulane = lane;
-  const long long ie_s = element_of_block(k, blockIdx.x);
+  const long long ie_s = element_of_block(k, WGW ? blockIdx.x / WG_PER_ELEM : blockIdx.x);
   if (ie_s < 0) return;
   const size_t ie = (size_t)ie_s, tl = (size_t)k.timelevels;
   const size_t wb = (size_t)w * (TPW * 64);
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(NLEV * PP / 64 / TPW * 64) void traffic_skeleton_np
       st<NTS>(eta + off, et[r] + 0.0);
     }
   }
-  if (tid < PP) eta_last[ulane] = eta_last[ulane] + 0.0;
+  if (w == 0 && lane < PP) eta_last[ulane] = eta_last[ulane] + 0.0;
 }
 
 // Same bytes as traffic_skeleton_np4<NLEV, 2, ...> but every access 16 bytes per lane: the two
@@ -282,6 +301,13 @@ hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, i
       case 10: skel<72, 2, 2, 1, true>(k, num_elems, s); break;
       case 11: skel<72, 2, 1, 2, true>(k, num_elems, s); break;
       case 12: skel<72, 2, 2, 2, true>(k, num_elems, s); break;
+      // small workgroups: <TPW, WGW> -> (18 / TPW / WGW) workgroups of WGW waves per element
+      case 15: hipLaunchKernelGGL((traffic_skeleton_np4<72, 1, 1, 1, true, 16, 1>), dim3(num_elems * 18), dim3(64), 0, s, k); break;
+      case 16: hipLaunchKernelGGL((traffic_skeleton_np4<72, 2, 1, 1, true, 16, 1>), dim3(num_elems * 9), dim3(64), 0, s, k); break;
+      case 17: hipLaunchKernelGGL((traffic_skeleton_np4<72, 1, 1, 1, true, 16, 2>), dim3(num_elems * 9), dim3(128), 0, s, k); break;
+      case 18: hipLaunchKernelGGL((traffic_skeleton_np4<72, 1, 1, 1, true, 16, 6>), dim3(num_elems * 3), dim3(384), 0, s, k); break;
+      case 19: hipLaunchKernelGGL((traffic_skeleton_np4<72, 2, 1, 1, true, 16, 3>), dim3(num_elems * 3), dim3(192), 0, s, k); break;
+      case 20: hipLaunchKernelGGL((traffic_skeleton_np4<72, 1, 1, 1, false, 16, 1>), dim3(num_elems * 18), dim3(64), 0, s, k); break;
       case 13: hipLaunchKernelGGL((traffic_skeleton_np4_w16<72, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(576), 0, s, k); break;
       case 14: hipLaunchKernelGGL((traffic_skeleton_np4_w16<72, 0>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(576), 0, s, k); break;
       default: return hipErrorInvalidValue;
