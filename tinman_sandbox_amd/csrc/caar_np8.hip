@@ -12,8 +12,10 @@
 //   * the 8x8 Dvv contractions go through a wave-private 512 B LDS tile: the field is
 //     written once and each lane reads its row (4 x ds_read_b128) or column
 //     (8 x ds_read_b64); Dvv is staged transposed in LDS so that both coefficient
-//     vectors are contiguous.  fp64 MFMA was not used: on MI355X v_mfma_f64 runs at
-//     the vector fp64 rate and an 8x8 operand fills half of its 16x16 tile.
+//     vectors are contiguous.  That is the direct form (variants 2..); the DEFAULT form (MFMA = true)
+//     runs the contractions on v_mfma_f64_4x4x4 with the lane -> point mapping of the MFMA result
+//     layout and no LDS tile at all (caar_np8_ops.h "MFMA form"): measured 1 % faster A/B
+//     (profiles/r02/kbench_np8_nlev72_mfma.log).
 //   * an NP=8 element does not fit the register file the way an NP=4 one does (7 live
 //     values x 64 points x 72 levels = 258 KB): between the phases dp, u, v, T of every
 //     level are read through a two-deep prefetch ring, dp, u, v are parked in LDS
@@ -32,7 +34,12 @@ namespace caar {
 // VADV: the Eulerian vertical coordinate (rsplit == 0), see caar_np4.hip.  u and v of the
 // neighbouring levels are already in the LDS park; T of the level above a wave's first and
 // below its last level goes through a small LDS halo.
-template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T, bool BATCH, bool VADV = false>
+//
+// MFMA: the 8x8 contractions go through v_mfma_f64_4x4x4 (caar_np8_ops.h "MFMA form"): the lane -> GLL point
+// mapping becomes the MFMA result layout (mfma_point), the wave-private LDS tile and the LDS Dvv copy are not
+// used at all, everything else is unchanged.
+// LA: how many levels ahead the update-phase inputs (nm1 state, vn0, omega_p, pecnd, eta) are requested.
+template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T, bool BATCH, bool VADV = false, bool MFMA = false, int LA = 1>
 __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const KernelArgs k) {
   using namespace np8;
   constexpr int WAVES = NLEV / TPW;
@@ -40,11 +47,12 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   constexpr int BLK = NLEV * PP;
   static_assert(NLEV % TPW == 0 && THREADS <= 1024, "level decomposition");
   static_assert(!VADV || !RELOAD_T, "Eulerian branch keeps T in registers");
+  static_assert(!MFMA || (!BATCH && !COEF_LDS), "MFMA form: no LDS tile, Dvv slices are per-lane MFMA operands");
 
   __shared__ __attribute__((aligned(16))) double s_dvvT[64];
   __shared__ __attribute__((aligned(16))) double s_geo[G_SIZE];
   constexpr int SLOTS = BATCH ? 5 : 1;  // LDS tile slots per wave (BATCH: p, T, Ephi, vcov1, vcov0)
-  __shared__ __attribute__((aligned(16))) double s_tile[WAVES * 64 * SLOTS];
+  __shared__ __attribute__((aligned(16))) double s_tile[MFMA ? 1 : WAVES * 64 * SLOTS];
   __shared__ double s_park[3 * BLK + (VADV ? PP : 0)];  // dp, u, v of every level, [field][lev][pt] (+ a zero row for VADV)
   __shared__ double s_tot_dp[WAVES * PP];   // per wave: sum of dp over its levels
   __shared__ double s_tot_div[WAVES * PP];  // ... of divdp
@@ -54,7 +62,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pt = lane;
+  const int pt = MFMA ? mfma_point(lane) : lane;  // GLL point a*8+b of this lane
   const long long ie_s = element_of_block(k, blockIdx.x);
   if (ie_s < 0) return;  // padding block of the XCD-chunked grid (uniform for the workgroup)
   const size_t ie = (size_t)ie_s;
@@ -62,7 +70,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   const int lev0 = w * TPW;
   // Addressing as in caar_np4.hip: wave-uniform field pointers (element, time level and
   // this wave's first level folded in) indexed by `r * PP + ulane`, r compile-time.
-  const unsigned ulane = lane;
+  const unsigned ulane = pt;  // offset of this lane's point inside a level
   const size_t wbase = (size_t)lev0 * PP;
 
   const double* __restrict__ dp_n0 = k.dp3d + (ie * tl + k.n0) * BLK + wbase;
@@ -107,8 +115,10 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   }
   __syncthreads();
 
+  MfmaCtx mc;
+  if (MFMA) mc = make_mfma_ctx(k.Dvv, lane);
   Ctx c;
-  c.tile = s_tile + w * 64 * SLOTS;
+  c.tile = s_tile + (MFMA ? 0 : w * 64 * SLOTS);
   c.a = lane >> 3;
   c.b = lane & 7;
   c.dvvT = s_dvvT;
@@ -141,6 +151,8 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
         c.tile[64 + lane] = gv1;
         wave_lds_fence();
         divdp[r] = (d_da_slot<COEF_LDS>(c, 0) + d_db_slot<COEF_LDS>(c, 1)) * rmetdet * rrearth;  // S:81-85
+      } else if (MFMA) {
+        divdp[r] = divergence_sphere_mfma(mc, Dinv, metdet, rmetdet, rrearth, x.uv.x * x.dp, x.uv.y * x.dp);  // P:114-121
       } else {
         divdp[r] = divergence_sphere<COEF_LDS>(c, lane, Dinv, metdet, rmetdet, rrearth, x.uv.x * x.dp, x.uv.y * x.dp);  // P:114-121
       }
@@ -190,7 +202,10 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     x.Tn0 = RELOAD_T ? stream_load<SNT>(T_n0 + off) : 0.0;
     return x;
   };
-  LevelIn cur = load_level(0);  // requested before phase 2: in flight across it and the barrier
+  static_assert(LA >= 1 && LA <= TPW, "look-ahead");
+  LevelIn ahead[LA];  // requested before phase 2: in flight across it and the barrier
+#pragma unroll
+  for (int r = 0; r < LA; ++r) ahead[r] = load_level(r);
 
   // ---- phase 2: hydrostatic increments, their suffix sums inside the wave ---------------
   double base_dp = 0.0, base_div = 0.0;  // sums over the levels above this wave's first level
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   }
 
   double l_eta_last = 0.0;
-  if (tid < PP) l_eta_last = eta_last[ulane];
+  if (tid < PP) l_eta_last = eta_last[tid];
   __syncthreads();
 
   // ---- phase 3: level-local tendencies and update, top level of the wave first ----------
@@ -229,8 +244,8 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
 #pragma unroll
   for (int r = 0; r < TPW; ++r) {
     const unsigned off = r * PP + ulane;
-    LevelIn nxt = cur;
-    if (r + 1 < TPW) nxt = load_level(r + 1);
+    const LevelIn cur = ahead[r % LA];
+    if (r + LA < TPW) ahead[r % LA] = load_level(r + LA);
 
     // The metric terms are re-read from LDS at every level instead of living in 26 registers
     // for the whole phase; the empty asm makes the pointer opaque so the loads are not hoisted.
@@ -274,6 +289,11 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
       gE0 = Dinv.m00 * ea + Dinv.m10 * eb;
       gE1 = Dinv.m01 * ea + Dinv.m11 * eb;
       vort = (d_da_slot<COEF_LDS>(c, 3) - d_db_slot<COEF_LDS>(c, 4)) * rmetdet * rrearth;  // S:121-125
+    } else if (MFMA) {
+      gradient_sphere_mfma(mc, Dinv, rrearth, p, gp0, gp1);              // P:103
+      vort = vorticity_sphere_mfma(mc, Dm, rmetdet, rrearth, ur, vr);    // P:122
+      gradient_sphere_mfma(mc, Dinv, rrearth, Tr, gT0, gT1);             // P:200
+      gradient_sphere_mfma(mc, Dinv, rrearth, Ephi, gE0, gE1);           // P:213
     } else {
       gradient_sphere<COEF_LDS>(c, lane, Dinv, rrearth, p, gp0, gp1);    // P:103
       vort = vorticity_sphere<COEF_LDS>(c, lane, Dm, rmetdet, rrearth, ur, vr);  // P:122
@@ -334,39 +354,43 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     vn.y = cur.vn0.y + k.eta_ave_w * (vr * dpr);                       // P:118
     stream_store<SNT>(vn0 + off, vn);
     stream_store<SNT>(eta + off, cur.eta + (VADV ? k.eta_ave_w * eta_lo : eta_zero));  // P:172, X:271-272
-    cur = nxt;
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (tid < PP) eta_last[ulane] = l_eta_last + eta_zero;               // P:181
+  if (tid < PP) eta_last[tid] = l_eta_last + eta_zero;                 // P:181
 }
 
-template <int NLEV, int TPW, int MINW, bool NT, bool COEF_LDS = false, bool RELOAD_T = false, bool BATCH = false>
+template <int NLEV, int TPW, int MINW, bool NT, bool COEF_LDS = false, bool RELOAD_T = false, bool BATCH = false, bool MFMA = false, int LA = 1>
 static hipError_t launch_np8(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = NLEV / TPW * 64;
   const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
   if (k.vadv) {  // rsplit == 0: T stays in registers (no RELOAD_T form)
     if (k.qn0 >= 0)
-      hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT, COEF_LDS, false, BATCH, true>), dim3(grid), dim3(THREADS), 0, stream, k);
+      hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT, COEF_LDS, false, BATCH, true, MFMA>), dim3(grid), dim3(THREADS), 0, stream, k);
     else
-      hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false, NT, COEF_LDS, false, BATCH, true>), dim3(grid), dim3(THREADS), 0, stream, k);
+      hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false, NT, COEF_LDS, false, BATCH, true, MFMA>), dim3(grid), dim3(THREADS), 0, stream, k);
     return hipGetLastError();
   }
   if (k.qn0 >= 0)
-    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT, COEF_LDS, RELOAD_T, BATCH>), dim3(grid), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT, COEF_LDS, RELOAD_T, BATCH, false, MFMA, LA>), dim3(grid), dim3(THREADS), 0, stream, k);
   else  // dry branch (P:128-139)
-    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false, NT, COEF_LDS, RELOAD_T, BATCH>), dim3(grid), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false, NT, COEF_LDS, RELOAD_T, BATCH, false, MFMA, LA>), dim3(grid), dim3(THREADS), 0, stream, k);
   return hipGetLastError();
 }
 
 // (non-const on purpose, see caar_np4.hip)
 KernelVariant kNp8Nlev72[] = {
-    {"caar_np8_kernel<72, 9, 1, true, true, true, false, false, false>", "8 waves x 9 levels, nt, Dvv slices re-read from LDS", launch_np8<72, 9, 1, true, true, false, false>},
-    {"caar_np8_kernel<72, 9, 1, true, true, true, false, true, false>", "8 waves x 9 levels, nt, Dvv slices from LDS, operators batched per level", launch_np8<72, 9, 1, true, true, false, true>},
-    {"caar_np8_kernel<72, 9, 1, true, true, true, true, true, false>", "8 waves x 9 levels, nt, Dvv slices from LDS, T re-read, operators batched", launch_np8<72, 9, 1, true, true, true, true>},
-    {"caar_np8_kernel<72, 9, 1, true, true, true, true, false, false>", "8 waves x 9 levels, nt, Dvv slices from LDS, T re-read in the last phase", launch_np8<72, 9, 1, true, true, true, false>},
-    {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false>", "8 waves x 9 levels, nt, Dvv slices in registers", launch_np8<72, 9, 1, true, false, false, false>},
-    {"caar_np8_kernel<72, 9, 1, true, false, true, false, false, false>", "8 waves x 9 levels, default cache policy", launch_np8<72, 9, 1, false, true, false, false>},
-    {"caar_np8_kernel<72, 18, 1, true, true, false, false, true, false>", "4 waves x 18 levels (one wave per SIMD), nt, operators batched", launch_np8<72, 18, 1, true, false, false, true>},
+    {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, true, 2>", "8 waves x 9 levels, nt, MFMA contractions, update-phase inputs requested two levels ahead", launch_np8<72, 9, 1, true, false, false, false, true, 2>},
+    {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, true, 1>", "8 waves x 9 levels, nt, Dvv contractions on v_mfma_f64_4x4x4 (lane = MFMA result layout, no LDS tile)", launch_np8<72, 9, 1, true, false, false, false, true>},
+    {"caar_np8_kernel<72, 9, 1, true, true, true, false, false, false, false, 1>", "8 waves x 9 levels, nt, Dvv slices re-read from LDS", launch_np8<72, 9, 1, true, true, false, false>},
+    {"caar_np8_kernel<72, 9, 1, true, true, true, false, true, false, false, 1>", "8 waves x 9 levels, nt, Dvv slices from LDS, operators batched per level", launch_np8<72, 9, 1, true, true, false, true>},
+    {"caar_np8_kernel<72, 9, 1, true, true, true, true, true, false, false, 1>", "8 waves x 9 levels, nt, Dvv slices from LDS, T re-read, operators batched", launch_np8<72, 9, 1, true, true, true, true>},
+    {"caar_np8_kernel<72, 9, 1, true, true, true, true, false, false, false, 1>", "8 waves x 9 levels, nt, Dvv slices from LDS, T re-read in the last phase", launch_np8<72, 9, 1, true, true, true, false>},
+    {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, false, 1>", "8 waves x 9 levels, nt, Dvv slices in registers", launch_np8<72, 9, 1, true, false, false, false>},
+    {"caar_np8_kernel<72, 9, 1, true, false, true, false, false, false, false, 1>", "8 waves x 9 levels, default cache policy", launch_np8<72, 9, 1, false, true, false, false>},
+    {"caar_np8_kernel<72, 18, 1, true, true, false, false, true, false, false, 1>", "4 waves x 18 levels (one wave per SIMD), nt, operators batched", launch_np8<72, 18, 1, true, false, false, true>},
+    {"caar_np8_kernel<72, 9, 1, true, true, false, true, false, false, true, 1>", "8 waves x 9 levels, nt, MFMA contractions, T re-read in the last phase", launch_np8<72, 9, 1, true, false, true, false, true>},
+    {"caar_np8_kernel<72, 12, 1, true, true, false, false, false, false, true, 1>", "6 waves x 12 levels, nt, MFMA contractions", launch_np8<72, 12, 1, true, false, false, false, true>},
+    {"caar_np8_kernel<72, 9, 1, true, true, false, true, false, false, true, 2>", "8 waves x 9 levels, nt, MFMA contractions, T re-read, update-phase inputs two levels ahead", launch_np8<72, 9, 1, true, false, true, false, true, 2>},
 };
 int kNp8Nlev72Count = sizeof(kNp8Nlev72) / sizeof(kNp8Nlev72[0]);
 

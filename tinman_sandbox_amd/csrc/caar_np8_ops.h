@@ -119,6 +119,91 @@ __device__ __forceinline__ double vorticity_sphere(const Ctx& c, int lane, const
   return (dvdx - dudy) * rmetdet * rrearth;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// MFMA form of the two 8x8 contractions (BASELINE north_star: "MFMA used only for the batched Dvv
+// contraction when NP >= 8"): v_mfma_f64_4x4x4_4b_f64, four independent 4x4x4 products per issue, so an
+// 8x8 * 8x8 product is its 2x2 output blocks x 2 k-blocks = two issues, no padding, no wasted lanes
+// (the 16x16x4 form would carry an 8-row operand in a 16-row tile: half of every issue multiplies zeros).
+// Operand layouts measured on gfx950 (tools/probes/mfma_f64_probe.hip, profiles/r02/mfma_probe.log):
+//     A[blk][i][k] in lane 16k + 4blk + i,   B[blk][k][j] in lane 16k + 4blk + j,   D[blk][i][j] in lane 16i + 4blk + j.
+// With blk = 2I + J the result D_(I,J)[i][j] = M[4I+i][4J+j] of an 8x8 matrix M sits in lane 16i + 8I + 4J + j.
+// The kernel adopts exactly that as its lane -> GLL point mapping (mfma_point): results land where the
+// pointwise code needs them, every 8-lane group is still one contiguous 64-byte row of the level.
+//   d/da = Dvv^T . F :  A = blocks of Dvv^T (two per-lane constants), B = blocks of F: lane (k, I, J, j) needs
+//          F[4K+k][4J+j], i.e. its own value or the one 8 lanes away in its 16-lane row -> one bank-masked
+//          DPP row_ror:8 per k-block, no LDS.
+//   d/db = F . Dvv   :  B = blocks of Dvv (two per-lane constants), A = blocks of F in the TRANSPOSED in-block
+//          placement (row index in the low lane bits): one ds_bpermute per k-block (crossbar only, no LDS memory).
+// Against the direct form per field pair: 4 MFMA + 4 DPP movs + 4 ds_bpermute_b32 instead of 16 fp64 FMAs,
+// one ds_write_b64, four ds_read_b128 and eight ds_read_b64.
+__device__ __forceinline__ int mfma_point(int lane) {
+  const int a = 4 * ((lane >> 3) & 1) + (lane >> 4), b = lane & 7;
+  return a * NP + b;
+}
+
+struct MfmaCtx {
+  double a_da[2];  // A operand of d/da for k-block K: Dvv[4K + h][4I + l]     (lane = 16h + 8I + 4J + l)
+  double b_db[2];  // B operand of d/db for k-block K: Dvv[4K + h][4J + l]
+  int src_db[2];   // lane that holds F[4I + l][4K + h]: 16l + 8I + 4K + h
+};
+
+__device__ __forceinline__ MfmaCtx make_mfma_ctx(const double* dvv /* Dvv[k][j] row-major, any address space */, int lane) {
+  const int h = lane >> 4, I = (lane >> 3) & 1, J = (lane >> 2) & 1, l = lane & 3;
+  MfmaCtx c;
+#pragma unroll
+  for (int K = 0; K < 2; ++K) {
+    c.a_da[K] = dvv[(4 * K + h) * NP + 4 * I + l];
+    c.b_db[K] = dvv[(4 * K + h) * NP + 4 * J + l];
+    c.src_db[K] = 16 * l + 8 * I + 4 * K + h;
+  }
+  return c;
+}
+
+// DPP move whose result is taken only by the lanes of the enabled 4-lane banks of each 16-lane row; the
+// others keep x (dpp_ctrl 0x128 = row_ror:8: the value 8 lanes away in the row).
+template <int BANK_MASK>
+__device__ __forceinline__ double swap8_banked(double x) {
+  return __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, BANK_MASK, false);
+}
+
+__device__ __forceinline__ double mfma4(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+// sum_k Dvv[k][a] f[k][b] at this lane's point (a, b)
+__device__ __forceinline__ double mfma_d_da(const MfmaCtx& c, double f) {
+  const double b0 = swap8_banked<0xC>(f);  // block row K = 0: lanes 8..15 of each row take lane - 8's value
+  const double b1 = swap8_banked<0x3>(f);  // block row K = 1: lanes 0..7 take lane + 8's value
+  return mfma4(c.a_da[1], b1, mfma4(c.a_da[0], b0, 0.0));
+}
+// sum_k Dvv[k][b] f[a][k]
+__device__ __forceinline__ double mfma_d_db(const MfmaCtx& c, double f) {
+  const double a0 = __shfl(f, c.src_db[0], 64);
+  const double a1 = __shfl(f, c.src_db[1], 64);
+  return mfma4(a1, c.b_db[1], mfma4(a0, c.b_db[0], 0.0));
+}
+
+// the three operators, S:9-129, on top of the MFMA contractions
+__device__ __forceinline__ void gradient_sphere_mfma(const MfmaCtx& c, const M22& Dinv, double rrearth, double s,
+                                                     double& g0, double& g1) {
+  const double v1 = mfma_d_da(c, s) * rrearth;
+  const double v2 = mfma_d_db(c, s) * rrearth;
+  g0 = Dinv.m00 * v1 + Dinv.m10 * v2;
+  g1 = Dinv.m01 * v1 + Dinv.m11 * v2;
+}
+__device__ __forceinline__ double divergence_sphere_mfma(const MfmaCtx& c, const M22& Dinv, double metdet, double rmetdet,
+                                                         double rrearth, double u, double v) {
+  const double gv0 = metdet * (Dinv.m00 * u + Dinv.m01 * v);
+  const double gv1 = metdet * (Dinv.m10 * u + Dinv.m11 * v);
+  return (mfma_d_da(c, gv0) + mfma_d_db(c, gv1)) * rmetdet * rrearth;
+}
+__device__ __forceinline__ double vorticity_sphere_mfma(const MfmaCtx& c, const M22& D, double rmetdet, double rrearth,
+                                                        double u, double v) {
+  const double vc0 = D.m00 * u + D.m10 * v;
+  const double vc1 = D.m01 * u + D.m11 * v;
+  return (mfma_d_da(c, vc1) - mfma_d_db(c, vc0)) * rmetdet * rrearth;
+}
+
 }  // namespace np8
 
 }  // namespace caar
