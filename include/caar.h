@@ -150,6 +150,71 @@ int caar_sphere_operator_range(const CaarDims *dims, const CaarArrays *dev, cons
                                int e0, int e1, int nlevels, const double *in_dev, double *out_dev,
                                double rrearth, void *stream);
 
+/* ---- the sphere operators next to the CAAR path ---------------------------------
+ * Reference: cxx/level_vectorized_ppscan/SphereOperators.hpp:271-993 (Kokkos device functions the reference
+ * defines but never builds, calls or tests: their parity is UNPINNED, see oracle/sphere_ops_oracle.c).
+ * Same batching as caar_sphere_operator_range: elements [e0, e1), `nlevels` fields per element,
+ * in/out [e - e0][lev][np][np] (scalar) or [e - e0][lev][np][np][2] (vector), this repository's index
+ * convention (field[a][b] == Fortran (a+1, b+1), as the pointers_only arrays).
+ *   code                                   in -> out        geometry read                       reference
+ *   0  GRADIENT_SPHERE                     s  -> v          Dinv                                 K:229-269
+ *   1  DIVERGENCE_SPHERE                   v  -> s          Dinv, metdet, rmetdet                K:315-358
+ *   2  VORTICITY_SPHERE (vector input)     v  -> s          D, rmetdet                           K:452-490
+ *   3  DIVERGENCE_SPHERE_WK                v  -> s          Dinv, spheremp                       K:494-534
+ *   4  LAPLACE_SIMPLE                      s  -> s          Dinv, spheremp                       K:538-550
+ *   5  LAPLACE_TENSOR                      s  -> s          Dinv, spheremp, tensorVisc           K:556-596
+ *   6  CURL_SPHERE_WK_TESTCOV              s  -> v          D, mp                                K:640-690
+ *   7  GRAD_SPHERE_WK_TESTCOV              s  -> v          D, mp, metinv, metdet                K:694-770
+ *   8  VLAPLACE_SPHERE_WK_CONTRA           v  -> v          D, Dinv, mp, spheremp, metinv, metdet, rmetdet; nu_ratio   K:938-993
+ *   9  VLAPLACE_SPHERE_WK_CARTESIAN        v  -> v          Dinv, spheremp, tensorVisc, vec_sph2cart   K:849-915 (rigid-rotation term kept, K:891)
+ *   10 GRADIENT_SPHERE_UPDATE              s  -> v += grad  Dinv                                 K:271-312
+ *   11 DIVERGENCE_SPHERE_UPDATE            v  -> s = beta*s + alpha*div   Dinv, metdet, rmetdet  K:363-403
+ *   12 VLAPLACE_SPHERE_WK_CARTESIAN_DAMPED v  -> v          as 9, without the rigid-rotation term  K:777-844
+ * Codes 1, 2, 8, 11 multiply by rmetdet (the pointers_only operators' form, sphere_operators.cpp:85,125)
+ * where K: forms 1/metdet on the fly.  The EulerStep functor (EulerStepFunctor.hpp:32-68) is NOT provided:
+ * the reference's own call of divergence_sphere_update does not match its declaration. */
+enum {
+  CAAR_OP_GRADIENT_SPHERE = 0,
+  CAAR_OP_DIVERGENCE_SPHERE = 1,
+  CAAR_OP_VORTICITY_SPHERE = 2,
+  CAAR_OP_DIVERGENCE_SPHERE_WK = 3,
+  CAAR_OP_LAPLACE_SIMPLE = 4,
+  CAAR_OP_LAPLACE_TENSOR = 5,
+  CAAR_OP_CURL_SPHERE_WK_TESTCOV = 6,
+  CAAR_OP_GRAD_SPHERE_WK_TESTCOV = 7,
+  CAAR_OP_VLAPLACE_SPHERE_WK_CONTRA = 8,
+  CAAR_OP_VLAPLACE_SPHERE_WK_CARTESIAN = 9,
+  CAAR_OP_GRADIENT_SPHERE_UPDATE = 10,
+  CAAR_OP_DIVERGENCE_SPHERE_UPDATE = 11,
+  CAAR_OP_VLAPLACE_SPHERE_WK_CARTESIAN_DAMPED = 12,
+  CAAR_OP_COUNT = 13
+};
+/* Per-element geometry, DEVICE pointers to element 0, point-major with the components fastest like
+ * CaarArrays: D, Dinv, metinv, tensorVisc [ie][np][np][2][2]; metdet, rmetdet, spheremp, mp [ie][np][np];
+ * vec_sph2cart [ie][np][np][3][2].  Only the arrays the chosen operator reads (table above) must be set;
+ * the 2x2 / 3x2 ones must be 16-byte aligned. */
+typedef struct CaarOperatorGeometry {
+  const double *D, *Dinv, *metdet, *rmetdet, *spheremp, *mp, *metinv, *tensorVisc, *vec_sph2cart;
+} CaarOperatorGeometry;
+typedef struct CaarOperatorScalars {
+  double rrearth;
+  double alpha, beta; /* DIVERGENCE_SPHERE_UPDATE */
+  double nu_ratio;    /* VLAPLACE_SPHERE_WK_CONTRA */
+} CaarOperatorScalars;
+/* Asynchronous on `stream`.  in_dev / out_dev 16-byte aligned, not overlapping. */
+int caar_sphere_operator_ex(const CaarDims *dims, const CaarOperatorGeometry *geo, const double *dvv_dev, int which,
+                            int e0, int e1, int nlevels, const double *in_dev, double *out_dev,
+                            const CaarOperatorScalars *scalars, void *stream);
+
+/* The two vertical integrals of the path as functions of their own (reference:
+ * compute_and_apply_rhs.hpp:11-17, P:280-352), batched over `nelem` columns-of-elements:
+ * phis [e][np][np]; T_v, p, dp, phi, vgrad_p, divdp, omega_p [e][nlev][np][np] (device).  One thread per
+ * column in the reference's own order, no FMA contraction, IEEE division: bit-identical to the reference. */
+int caar_preq_hydrostatic(const CaarDims *dims, int nelem, const double *phis_dev, const double *T_v_dev,
+                          const double *p_dev, const double *dp_dev, double Rgas, double *phi_dev, void *stream);
+int caar_preq_omega_ps(const CaarDims *dims, int nelem, const double *p_dev, const double *vgrad_p_dev,
+                       const double *divdp_dev, double *omega_p_dev, void *stream);
+
 /* Numerics hook: out[i] = the kernels' reciprocal of in[i] (v_rcp_f64 + two Newton steps,
  * used for the divisions by p and dp3d, P:150,219,291,323; <= 1 ulp for normal inputs). */
 int caar_reciprocal(const double *in_dev, double *out_dev, long long n, void *stream);

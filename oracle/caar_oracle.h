@@ -117,6 +117,37 @@ void oracle_init_dvv_np4(double *Dvv, int f32_rounded);
  * the np=4 literals above to rounding. */
 void oracle_init_dvv_gll(int np, double *Dvv);
 
+/* ---- sphere operators next to the CAAR path, sphere_ops_oracle.c.  PARITY UNPINNED
+ * (see that file's header).  One np x np level per call; arrays in this repository's layout:
+ * scalar [np][np], vector [np][np][2], tensors [np][np][2][2], vec_sph2cart [np][np][3][2].
+ * K: = cxx/level_vectorized_ppscan/SphereOperators.hpp. */
+void oracle_k_gradient_sphere(int np, const double *s, const double *Dvv, const double *Dinv, double rrearth,
+                              double *grad);                                                   /* K:229-269 */
+void oracle_gradient_sphere_update(int np, const double *s, const double *Dvv, const double *Dinv, double rrearth,
+                                   double *grad);                                              /* K:271-312 */
+void oracle_k_divergence_sphere(int np, const double *v, const double *Dvv, const double *Dinv, const double *metdet,
+                                double rrearth, double *div);                                  /* K:315-358 */
+void oracle_divergence_sphere_update(int np, double alpha, double beta, const double *v, const double *Dvv,
+                                     const double *Dinv, const double *metdet, double rrearth, double *div); /* K:363-403 */
+void oracle_k_vorticity_sphere_vector(int np, const double *v, const double *Dvv, const double *D, const double *metdet,
+                                      double rrearth, double *vort);                           /* K:452-490 */
+void oracle_divergence_sphere_wk(int np, const double *v, const double *Dvv, const double *Dinv, const double *spheremp,
+                                 double rrearth, double *div);                                 /* K:494-534 */
+void oracle_laplace_simple(int np, const double *s, const double *Dvv, const double *Dinv, const double *spheremp,
+                           double rrearth, double *lap);                                       /* K:538-550 */
+void oracle_laplace_tensor(int np, const double *s, const double *Dvv, const double *Dinv, const double *spheremp,
+                           const double *tensorVisc, double rrearth, double *lap);             /* K:556-596 */
+void oracle_curl_sphere_wk_testcov(int np, const double *s, const double *Dvv, const double *D, const double *mp,
+                                   double rrearth, double *curls);                             /* K:640-690 */
+void oracle_grad_sphere_wk_testcov(int np, const double *s, const double *Dvv, const double *D, const double *mp,
+                                   const double *metinv, const double *metdet, double rrearth, double *grads); /* K:694-770 */
+void oracle_vlaplace_sphere_wk_cartesian(int np, const double *v, const double *Dvv, const double *Dinv,
+                                         const double *spheremp, const double *tensorVisc, const double *vec_sph2cart,
+                                         double rrearth, int undamp_rr, double *lap);          /* K:849-915 (K:777-844) */
+void oracle_vlaplace_sphere_wk_contra(int np, const double *v, const double *Dvv, const double *D, const double *Dinv,
+                                      const double *mp, const double *spheremp, const double *metinv, const double *metdet,
+                                      double nu_ratio, double rrearth, double *lap);           /* K:938-993 */
+
 #ifdef __cplusplus
 }
 #endif

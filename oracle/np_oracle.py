@@ -125,3 +125,75 @@ def compute_and_apply_rhs(arrs, Dvv, sc, dtype=np.float64):
     out["elem_state_dp3d"][sl, np1] = sph * (A["elem_state_dp3d"][sl, nm1] -
                                              dt2 * (divdp + eta_dot[:, 1:] - eta_dot[:, :-1]))
     return out
+
+
+# ---- sphere operators next to the CAAR path: a second, independent statement -------------------------------
+# Written from HOMME's Fortran formulas (derivative_mod: divergence_sphere_wk, laplace_sphere_wk,
+# curl_sphere_wk_testcov, gradient_sphere_wk_testcov, vlaplace_sphere_wk_contra / _cartesian) directly in this
+# repository's index convention (field[a][b] == Fortran (a+1, b+1), tensors [a][b][r][c] == Fortran
+# (., ., r+1, c+1), Dvv[i][j] == Fortran Dvv(i+1, j+1)) with einsum contractions — NOT through the accessor
+# macros of sphere_ops_oracle.c, so an index slip there does not repeat here.  Test infrastructure only.
+def ops_gradient_sphere(s, Dvv, Dinv, rr):
+    v1 = np.einsum("il,ij->lj", Dvv, s) * rr
+    v2 = np.einsum("il,ji->jl", Dvv, s) * rr
+    return np.stack([Dinv[..., 0, 0] * v1 + Dinv[..., 1, 0] * v2, Dinv[..., 0, 1] * v1 + Dinv[..., 1, 1] * v2], axis=-1)
+
+
+def ops_divergence_sphere(v, Dvv, Dinv, metdet, rr):
+    gv0 = metdet * (Dinv[..., 0, 0] * v[..., 0] + Dinv[..., 0, 1] * v[..., 1])
+    gv1 = metdet * (Dinv[..., 1, 0] * v[..., 0] + Dinv[..., 1, 1] * v[..., 1])
+    return (np.einsum("il,ij->lj", Dvv, gv0) + np.einsum("il,ji->jl", Dvv, gv1)) / metdet * rr
+
+
+def ops_vorticity_sphere(v, Dvv, D, metdet, rr):
+    vc0 = D[..., 0, 0] * v[..., 0] + D[..., 1, 0] * v[..., 1]
+    vc1 = D[..., 0, 1] * v[..., 0] + D[..., 1, 1] * v[..., 1]
+    return (np.einsum("il,ij->lj", Dvv, vc1) - np.einsum("il,ji->jl", Dvv, vc0)) / metdet * rr
+
+
+def ops_divergence_sphere_wk(v, Dvv, Dinv, spheremp, rr):
+    t0 = spheremp * (Dinv[..., 0, 0] * v[..., 0] + Dinv[..., 0, 1] * v[..., 1])
+    t1 = spheremp * (Dinv[..., 1, 0] * v[..., 0] + Dinv[..., 1, 1] * v[..., 1])
+    return -(np.einsum("mj,jn->mn", Dvv, t0) + np.einsum("nj,mj->mn", Dvv, t1)) * rr
+
+
+def ops_laplace_tensor(s, Dvv, Dinv, spheremp, tensorVisc, rr):
+    g = ops_gradient_sphere(s, Dvv, Dinv, rr)
+    if tensorVisc is not None:
+        g = np.stack([tensorVisc[..., 0, 0] * g[..., 0] + tensorVisc[..., 0, 1] * g[..., 1],
+                      tensorVisc[..., 1, 0] * g[..., 0] + tensorVisc[..., 1, 1] * g[..., 1]], axis=-1)
+    return ops_divergence_sphere_wk(g, Dvv, Dinv, spheremp, rr)
+
+
+def _cov_to_sphere(D, c0, c1, rr):
+    return np.stack([D[..., 0, 0] * c0 + D[..., 0, 1] * c1, D[..., 1, 0] * c0 + D[..., 1, 1] * c1], axis=-1) * rr
+
+
+def ops_curl_sphere_wk_testcov(s, Dvv, D, mp, rr):
+    ms = mp * s
+    return _cov_to_sphere(D, -np.einsum("nj,mj->mn", Dvv, ms), np.einsum("mj,jn->mn", Dvv, ms), rr)
+
+
+def ops_grad_sphere_wk_testcov(s, Dvv, D, mp, metinv, metdet, rr):
+    ms = mp * s
+    A = np.einsum("mj,jn->mn", Dvv, ms)
+    B = np.einsum("nj,mj->mn", Dvv, ms)
+    c0 = -(metinv[..., 0, 0] * metdet * A + metinv[..., 1, 0] * metdet * B)
+    c1 = -(metinv[..., 0, 1] * metdet * A + metinv[..., 1, 1] * metdet * B)
+    return _cov_to_sphere(D, c0, c1, rr)
+
+
+def ops_vlaplace_sphere_wk_contra(v, Dvv, D, Dinv, mp, spheremp, metinv, metdet, nu_ratio, rr):
+    div = ops_divergence_sphere(v, Dvv, Dinv, metdet, rr) * nu_ratio
+    vort = ops_vorticity_sphere(v, Dvv, D, metdet, rr)
+    return (2.0 * spheremp[..., None] * v * rr * rr + ops_grad_sphere_wk_testcov(div, Dvv, D, mp, metinv, metdet, rr)
+            - ops_curl_sphere_wk_testcov(vort, Dvv, D, mp, rr))
+
+
+def ops_vlaplace_sphere_wk_cartesian(v, Dvv, Dinv, spheremp, tensorVisc, s2c, rr, undamp_rr=True):
+    lap = [ops_laplace_tensor(s2c[..., k, 0] * v[..., 0] + s2c[..., k, 1] * v[..., 1], Dvv, Dinv, spheremp, tensorVisc, rr)
+           for k in range(3)]
+    out = np.stack([sum(s2c[..., k, h] * lap[k] for k in range(3)) for h in range(2)], axis=-1)
+    if undamp_rr:
+        out = out + 2.0 * spheremp[..., None] * v * rr * rr
+    return out

@@ -114,6 +114,19 @@ class Oracle:
         L.oracle_gradient_sphere.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, _dp]
         L.oracle_divergence_sphere.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp]
         L.oracle_vorticity_sphere.argtypes = [C.c_int, _dp, _dp, _dp, _dp, C.c_double, _dp]
+        d, i, f = _dp, C.c_int, C.c_double
+        for name, args in {
+                "oracle_k_gradient_sphere": [i, d, d, d, f, d], "oracle_gradient_sphere_update": [i, d, d, d, f, d],
+                "oracle_k_divergence_sphere": [i, d, d, d, d, f, d],
+                "oracle_divergence_sphere_update": [i, f, f, d, d, d, d, f, d],
+                "oracle_k_vorticity_sphere_vector": [i, d, d, d, d, f, d],
+                "oracle_divergence_sphere_wk": [i, d, d, d, d, f, d], "oracle_laplace_simple": [i, d, d, d, d, f, d],
+                "oracle_laplace_tensor": [i, d, d, d, d, d, f, d], "oracle_curl_sphere_wk_testcov": [i, d, d, d, d, f, d],
+                "oracle_grad_sphere_wk_testcov": [i, d, d, d, d, d, d, f, d],
+                "oracle_vlaplace_sphere_wk_cartesian": [i, d, d, d, d, d, d, f, i, d],
+                "oracle_vlaplace_sphere_wk_contra": [i, d, d, d, d, d, d, d, d, f, f, d]}.items():
+            getattr(L, name).argtypes = args
+            getattr(L, name).restype = None
 
     @staticmethod
     def _arrays(arrs):
@@ -189,6 +202,67 @@ class Oracle:
                                          _ptr(np.ascontiguousarray(D)), _ptr(np.ascontiguousarray(rmetdet)),
                                          rrearth, _ptr(out))
         return out
+
+
+# ---- sphere operators next to the CAAR path (sphere_ops_oracle.c; PARITY UNPINNED, see its header) ----------
+# name -> (input is a vector field, output is a vector field, geometry arrays in call order)
+SPHERE_OPS = {
+    "gradient_sphere": (False, True, ("Dinv",)),
+    "divergence_sphere": (True, False, ("Dinv", "metdet")),
+    "vorticity_sphere_vector": (True, False, ("D", "metdet")),
+    "divergence_sphere_wk": (True, False, ("Dinv", "spheremp")),
+    "laplace_simple": (False, False, ("Dinv", "spheremp")),
+    "laplace_tensor": (False, False, ("Dinv", "spheremp", "tensorVisc")),
+    "curl_sphere_wk_testcov": (False, True, ("D", "mp")),
+    "grad_sphere_wk_testcov": (False, True, ("D", "mp", "metinv", "metdet")),
+    "vlaplace_sphere_wk_cartesian": (True, True, ("Dinv", "spheremp", "tensorVisc", "vec_sph2cart")),
+    "vlaplace_sphere_wk_contra": (True, True, ("D", "Dinv", "mp", "spheremp", "metinv", "metdet")),
+    "gradient_sphere_update": (False, True, ("Dinv",)),
+    "divergence_sphere_update": (True, False, ("Dinv", "metdet")),
+}
+
+
+def sphere_op(O, name, x, Dvv, geo, rrearth, out=None, alpha=1.0, beta=0.0, nu_ratio=1.0, undamp_rr=1):
+    """One level of one element through the C oracle.  x: [np][np] or [np][np][2]; geo: dict of that element's
+    geometry arrays ([np][np], [np][np][2][2], vec_sph2cart [np][np][3][2]); `out` is the array the *_update
+    operators accumulate into (copied, not modified)."""
+    vin, vout, gnames = SPHERE_OPS[name]
+    np_ = x.shape[0]
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    Dvv = np.ascontiguousarray(Dvv, dtype=np.float64)
+    g = [np.ascontiguousarray(geo[n], dtype=np.float64) for n in gnames]
+    res = np.zeros((np_, np_, 2) if vout else (np_, np_)) if out is None else np.array(out, dtype=np.float64, order="C")
+    L = O.lib
+    P = _ptr
+    if name == "gradient_sphere":
+        L.oracle_k_gradient_sphere(np_, P(x), P(Dvv), P(g[0]), rrearth, P(res))
+    elif name == "gradient_sphere_update":
+        L.oracle_gradient_sphere_update(np_, P(x), P(Dvv), P(g[0]), rrearth, P(res))
+    elif name == "divergence_sphere":
+        L.oracle_k_divergence_sphere(np_, P(x), P(Dvv), P(g[0]), P(g[1]), rrearth, P(res))
+    elif name == "divergence_sphere_update":
+        L.oracle_divergence_sphere_update(np_, alpha, beta, P(x), P(Dvv), P(g[0]), P(g[1]), rrearth, P(res))
+    elif name == "vorticity_sphere_vector":
+        L.oracle_k_vorticity_sphere_vector(np_, P(x), P(Dvv), P(g[0]), P(g[1]), rrearth, P(res))
+    elif name == "divergence_sphere_wk":
+        L.oracle_divergence_sphere_wk(np_, P(x), P(Dvv), P(g[0]), P(g[1]), rrearth, P(res))
+    elif name == "laplace_simple":
+        L.oracle_laplace_simple(np_, P(x), P(Dvv), P(g[0]), P(g[1]), rrearth, P(res))
+    elif name == "laplace_tensor":
+        L.oracle_laplace_tensor(np_, P(x), P(Dvv), P(g[0]), P(g[1]), P(g[2]), rrearth, P(res))
+    elif name == "curl_sphere_wk_testcov":
+        L.oracle_curl_sphere_wk_testcov(np_, P(x), P(Dvv), P(g[0]), P(g[1]), rrearth, P(res))
+    elif name == "grad_sphere_wk_testcov":
+        L.oracle_grad_sphere_wk_testcov(np_, P(x), P(Dvv), P(g[0]), P(g[1]), P(g[2]), P(g[3]), rrearth, P(res))
+    elif name == "vlaplace_sphere_wk_cartesian":
+        L.oracle_vlaplace_sphere_wk_cartesian(np_, P(x), P(Dvv), P(g[0]), P(g[1]), P(g[2]), P(g[3]), rrearth,
+                                              int(undamp_rr), P(res))
+    elif name == "vlaplace_sphere_wk_contra":
+        L.oracle_vlaplace_sphere_wk_contra(np_, P(x), P(Dvv), P(g[0]), P(g[1]), P(g[2]), P(g[3]), P(g[4]), P(g[5]),
+                                           nu_ratio, rrearth, P(res))
+    else:
+        raise KeyError(name)
+    return res
 
 
 def ref_lib_path(np_, nlev):

@@ -55,11 +55,31 @@ class CaarError(RuntimeError):
     pass
 
 
+class _CaarOperatorGeometry(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("D", "Dinv", "metdet", "rmetdet", "spheremp", "mp", "metinv", "tensorVisc",
+                                           "vec_sph2cart")]
+
+
+class _CaarOperatorScalars(C.Structure):
+    _fields_ = [("rrearth", C.c_double), ("alpha", C.c_double), ("beta", C.c_double), ("nu_ratio", C.c_double)]
+
+
+# caar_sphere_operator_ex `which` codes (include/caar.h): name -> (code, vector input, vector output)
+SPHERE_OPERATORS = {
+    "gradient_sphere": (0, False, True), "divergence_sphere": (1, True, False), "vorticity_sphere": (2, True, False),
+    "divergence_sphere_wk": (3, True, False), "laplace_simple": (4, False, False), "laplace_tensor": (5, False, False),
+    "curl_sphere_wk_testcov": (6, False, True), "grad_sphere_wk_testcov": (7, False, True),
+    "vlaplace_sphere_wk_contra": (8, True, True), "vlaplace_sphere_wk_cartesian": (9, True, True),
+    "gradient_sphere_update": (10, False, True), "divergence_sphere_update": (11, True, False),
+    "vlaplace_sphere_wk_cartesian_damped": (12, True, True),
+}
+
+
 class CaarLibrary:
     """ctypes view of libcaar_hip.so; every symbol of include/caar.h is bound here."""
 
     SYMBOLS = ("caar_supported", "caar_abi_version", "caar_device_count", "caar_strerror", "caar_array_len",
-               "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator", "caar_sphere_operator_range", "caar_reciprocal",
+               "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator", "caar_sphere_operator_range", "caar_sphere_operator_ex", "caar_preq_hydrostatic", "caar_preq_omega_ps", "caar_reciprocal",
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
                "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_selected_variant", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_stream_copy_tuned", "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_create", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_download_f90",
                "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
@@ -89,6 +109,10 @@ class CaarLibrary:
                                            C.c_int, vp, vp, C.c_double, vp]
         L.caar_sphere_operator_range.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays), vp, C.c_int, C.c_int,
                                                  C.c_int, C.c_int, vp, vp, C.c_double, vp]
+        L.caar_sphere_operator_ex.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarOperatorGeometry), vp, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, vp, vp, C.POINTER(_CaarOperatorScalars), vp]
+        L.caar_preq_hydrostatic.argtypes = [C.POINTER(_CaarDims), C.c_int, vp, vp, vp, vp, C.c_double, vp, vp]
+        L.caar_preq_omega_ps.argtypes = [C.POINTER(_CaarDims), C.c_int, vp, vp, vp, vp, vp]
         L.caar_reciprocal.argtypes = [vp, vp, C.c_longlong, vp]
         L.caar_kernel_name.argtypes = [C.c_int, C.c_int]
         L.caar_kernel_name.restype = C.c_char_p
@@ -502,6 +526,43 @@ def sphere_operator_all(which, field, data, e0=0, e1=None):
                                              which, e0, e1, nl, C.c_void_p(f.data_ptr()), C.c_void_p(out.data_ptr()),
                                              data.constants.rrearth, C.c_void_p(stream.cuda_stream)),
             "caar_sphere_operator_range")
+    return out
+
+
+def sphere_operator_ex(name, field, geometry, Dvv, rrearth, out=None, alpha=1.0, beta=0.0, nu_ratio=1.0, e0=0):
+    """One of the sphere operators next to the CAAR path (caar_sphere_operator_ex; reference
+    level_vectorized_ppscan/SphereOperators.hpp:271-993) on device tensors: `field` [ne][nlevels][np][np](,2) for the
+    elements e0 .. e0+ne-1, `geometry` a dict of device tensors [num_elems][np][np](...) named as the members of
+    CaarOperatorGeometry (only those the operator reads), `Dvv` a device tensor [np][np].  `out` is the tensor the
+    *_update operators accumulate into (modified in place and returned)."""
+    L = library()
+    code, vin, vout = SPHERE_OPERATORS[name]
+    f = field.contiguous()
+    if not f.is_cuda or f.dtype != torch.float64:
+        raise CaarError("sphere_operator_ex needs float64 device tensors (no CPU fallback)")
+    ne, nl, np_ = f.shape[0], f.shape[1], f.shape[2]
+    assert tuple(f.shape) == ((ne, nl, np_, np_, 2) if vin else (ne, nl, np_, np_))
+    oshape = (ne, nl, np_, np_, 2) if vout else (ne, nl, np_, np_)
+    if out is None:
+        out = torch.empty(oshape, dtype=torch.float64, device=f.device)
+    assert tuple(out.shape) == oshape and out.is_contiguous() and out.dtype == torch.float64
+    g = _CaarOperatorGeometry()
+    keep = []
+    num_elems = None
+    for n, _ in _CaarOperatorGeometry._fields_:
+        t = geometry.get(n)
+        if t is not None:
+            t = t.contiguous()
+            keep.append(t)
+            num_elems = t.shape[0]
+            setattr(g, n, t.data_ptr())
+    dims = _CaarDims(np_, nl, 1, 1, num_elems if num_elems is not None else e0 + ne)
+    sc = _CaarOperatorScalars(rrearth, alpha, beta, nu_ratio)
+    dv = Dvv.contiguous()
+    stream = torch.cuda.current_stream(f.device)
+    L.check(L.lib.caar_sphere_operator_ex(C.byref(dims), C.byref(g), C.c_void_p(dv.data_ptr()), code, e0, e0 + ne, nl,
+                                          C.c_void_p(f.data_ptr()), C.c_void_p(out.data_ptr()), C.byref(sc),
+                                          C.c_void_p(stream.cuda_stream)), "caar_sphere_operator_ex")
     return out
 
 

@@ -38,6 +38,20 @@ hipError_t launch_sphere_operator(int np, int which, const double* in, double* o
                                   const double* Dinv, const double* metdet, const double* rmetdet,
                                   const double* dvv, int ie, int ne, int nlevels, double rrearth, hipStream_t s);
 hipError_t launch_reciprocal(const double* in, double* out, size_t n, hipStream_t s);
+struct OpArgs {  // caar_operators_ex.hip
+  const double *D, *Dinv, *metdet, *rmetdet, *spheremp, *mp, *metinv, *tensorVisc, *vec_sph2cart;
+  const double* dvv;
+  const double* in;
+  double* out;
+  int e0, ne, nlevels;
+  double rrearth, alpha, beta, nu_ratio;
+};
+hipError_t launch_sphere_operator_ex(int np, int which, const OpArgs& a, hipStream_t s);
+unsigned sphere_operator_ex_needs(int which);
+hipError_t launch_preq_hydrostatic(int np, int nlev, int nelem, const double* phis, const double* Tv, const double* p,
+                                   const double* dp, double Rgas, double* phi, hipStream_t s);
+hipError_t launch_preq_omega_ps(int np, int nlev, int nelem, const double* p, const double* vgrad_p, const double* divdp,
+                                double* omega_p, hipStream_t s);
 hipError_t launch_layout(double* dst, const double* src, size_t n, int np, int nc, int nlev, int qd,
                          int qdp_outer, bool to_caar, hipStream_t s);
 hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t stream);
@@ -384,6 +398,54 @@ int caar_sphere_operator_range(const CaarDims* dims, const CaarArrays* dev, cons
   return (int)caar::launch_sphere_operator(dims->np, which, in_dev, out_dev, dev->elem_D, dev->elem_Dinv,
                                            dev->elem_metdet, dev->elem_rmetdet, dvv_dev, e0, e1 - e0, nlevels,
                                            rrearth, (hipStream_t)stream);
+}
+
+int caar_sphere_operator_ex(const CaarDims* dims, const CaarOperatorGeometry* geo, const double* dvv_dev, int which,
+                            int e0, int e1, int nlevels, const double* in_dev, double* out_dev,
+                            const CaarOperatorScalars* sc, void* stream) {
+  if (!dims || !geo || !dvv_dev || !in_dev || !out_dev || !sc || nlevels < 0) return CAAR_EINVAL;
+  if (which < 0 || which >= CAAR_OP_COUNT) return CAAR_EINVAL;
+  if (e0 < 0 || e1 > dims->num_elems || e0 > e1) return CAAR_EINVAL;
+  if (dims->np != 4 && dims->np != 8) return CAAR_EUNSUPPORTED;
+  if ((((size_t)in_dev) | ((size_t)out_dev)) & 15) return CAAR_EINVAL;
+  const double* const* g = reinterpret_cast<const double* const*>(geo);
+  const unsigned needs = caar::sphere_operator_ex_needs(which);
+  for (int i = 0; i < 9; ++i) {
+    if (!((needs >> i) & 1)) continue;
+    if (!g[i]) return CAAR_EINVAL;
+    const bool wide = i == 0 || i == 1 || i >= 6;  // D, Dinv, metinv, tensorVisc, vec_sph2cart move as 16-byte pairs
+    if ((size_t)g[i] & (wide ? 15 : 7)) return CAAR_EINVAL;
+  }
+  caar::OpArgs a;
+  a.D = geo->D; a.Dinv = geo->Dinv; a.metdet = geo->metdet; a.rmetdet = geo->rmetdet; a.spheremp = geo->spheremp;
+  a.mp = geo->mp; a.metinv = geo->metinv; a.tensorVisc = geo->tensorVisc; a.vec_sph2cart = geo->vec_sph2cart;
+  a.dvv = dvv_dev;
+  a.in = in_dev;
+  a.out = out_dev;
+  a.e0 = e0;
+  a.ne = e1 - e0;
+  a.nlevels = nlevels;
+  a.rrearth = sc->rrearth;
+  a.alpha = sc->alpha;
+  a.beta = sc->beta;
+  a.nu_ratio = sc->nu_ratio;
+  return (int)caar::launch_sphere_operator_ex(dims->np, which, a, (hipStream_t)stream);
+}
+
+int caar_preq_hydrostatic(const CaarDims* dims, int nelem, const double* phis_dev, const double* T_v_dev,
+                          const double* p_dev, const double* dp_dev, double Rgas, double* phi_dev, void* stream) {
+  if (!dims || nelem < 0 || !phis_dev || !T_v_dev || !p_dev || !dp_dev || !phi_dev) return CAAR_EINVAL;
+  if (dims->np < 1 || dims->nlev < 2) return CAAR_EINVAL;
+  return (int)caar::launch_preq_hydrostatic(dims->np, dims->nlev, nelem, phis_dev, T_v_dev, p_dev, dp_dev, Rgas, phi_dev,
+                                            (hipStream_t)stream);
+}
+
+int caar_preq_omega_ps(const CaarDims* dims, int nelem, const double* p_dev, const double* vgrad_p_dev,
+                       const double* divdp_dev, double* omega_p_dev, void* stream) {
+  if (!dims || nelem < 0 || !p_dev || !vgrad_p_dev || !divdp_dev || !omega_p_dev) return CAAR_EINVAL;
+  if (dims->np < 1 || dims->nlev < 2) return CAAR_EINVAL;
+  return (int)caar::launch_preq_omega_ps(dims->np, dims->nlev, nelem, p_dev, vgrad_p_dev, divdp_dev, omega_p_dev,
+                                         (hipStream_t)stream);
 }
 
 int caar_reciprocal(const double* in_dev, double* out_dev, long long n, void* stream) {
