@@ -215,6 +215,20 @@ int caar_preq_hydrostatic(const CaarDims *dims, int nelem, const double *phis_de
 int caar_preq_omega_ps(const CaarDims *dims, int nelem, const double *p_dev, const double *vgrad_p_dev,
                        const double *divdp_dev, double *omega_p_dev, void *stream);
 
+/* The reference's operator functions with their own calling convention — HOST pointers, one np x np field of one
+ * element (one element's columns) in, one out, synchronous (sphere_operators.hpp:9-16: gradient_sphere /
+ * divergence_sphere / vorticity_sphere(field, data, ielem, out); compute_and_apply_rhs.hpp:11-17: preq_hydrostatic,
+ * preq_omega_ps).  `host` supplies elem_D, elem_Dinv, elem_metdet, elem_rmetdet as HOST arrays, dvv_host np*np
+ * doubles; which = 0/1/2 as caar_sphere_operator.  Each call uploads a few hundred bytes to a library-owned
+ * scratch area on device 0, launches the device operator and downloads the result: latency-bound by
+ * construction, thread-safe (mutex).  What Homme::gradient_sphere(...) etc. of the C++ shim call. */
+int caar_sphere_operator_host(const CaarDims *dims, const CaarArrays *host, const double *dvv_host, int which, int ie,
+                              const double *in_host, double *out_host, double rrearth);
+int caar_preq_hydrostatic_host(const CaarDims *dims, const double *phis, const double *T_v, const double *p,
+                               const double *dp, double Rgas, double *phi);
+int caar_preq_omega_ps_host(const CaarDims *dims, const double *p, const double *vgrad_p, const double *divdp,
+                            double *omega_p);
+
 /* Numerics hook: out[i] = the kernels' reciprocal of in[i] (v_rcp_f64 + two Newton steps,
  * used for the divisions by p and dp3d, P:150,219,291,323; <= 1 ulp for normal inputs). */
 int caar_reciprocal(const double *in_dev, double *out_dev, long long n, void *stream);

@@ -135,3 +135,27 @@ def test_reference_main_links_against_the_hip_path():
                           timeout=300).stdout
     b3 = norms_in(out3)
     assert np.allclose(b3[1], [18713.369259834482, 309464.50301779778, 138286.74685809007], rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize("np_,nlev", [(4, 72), (8, 72)])
+def test_shim_is_reentrant_and_defines_the_reference_operator_functions(tmp_path, np_, nlev):
+    """tests/host_reentrancy.cpp: four host threads calling Homme::compute_and_apply_rhs on disjoint [nets, nete)
+    of one TestData (own Control copies) reproduce the single-thread result bit for bit (SURVEY 8b "Threading");
+    Homme::gradient/divergence/vorticity_sphere and preq_hydrostatic/preq_omega_ps (the reference-signature host
+    functions of sphere_operators.hpp:9-16, compute_and_apply_rhs.hpp:11-17) against the oracle."""
+    from tinman_sandbox_amd import build
+    build.build_host_driver(np_=np_, nlev=nlev)
+    host = os.path.join(ROOT, "tinman_sandbox_amd", "host")
+    suffix = "" if (np_, nlev) == (4, 72) else "_np%d_nlev%d" % (np_, nlev)
+    exe = str(tmp_path / "host_reentrancy")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", "-DCAAR_NP=%d" % np_, "-DCAAR_PLEV=%d" % nlev,
+                    "-I" + os.path.join(ROOT, "include"), "-I" + host, "-I" + os.path.join(ROOT, "oracle"),
+                    os.path.join(ROOT, "tests", "host_reentrancy.cpp"),
+                    "-L" + host, "-lhomme_caar" + suffix, "-Wl,-rpath," + host,
+                    "-L" + os.path.join(ROOT, "oracle"), "-lcaar_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+                    "-L" + os.path.join(ROOT, "tinman_sandbox_amd", "csrc"), "-lcaar_hip",
+                    "-Wl,-rpath," + os.path.join(ROOT, "tinman_sandbox_amd", "csrc"), "-Wl,-rpath,/opt/rocm/lib",
+                    "-o", exe], check=True)
+    r = subprocess.run([exe, "37", "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert "== bitwise the single call" in r.stdout

@@ -79,7 +79,7 @@ class CaarLibrary:
     """ctypes view of libcaar_hip.so; every symbol of include/caar.h is bound here."""
 
     SYMBOLS = ("caar_supported", "caar_abi_version", "caar_device_count", "caar_strerror", "caar_array_len",
-               "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator", "caar_sphere_operator_range", "caar_sphere_operator_ex", "caar_preq_hydrostatic", "caar_preq_omega_ps", "caar_reciprocal",
+               "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator", "caar_sphere_operator_range", "caar_sphere_operator_ex", "caar_preq_hydrostatic", "caar_preq_omega_ps", "caar_sphere_operator_host", "caar_preq_hydrostatic_host", "caar_preq_omega_ps_host", "caar_reciprocal",
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
                "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_selected_variant", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_stream_copy_tuned", "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_create", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_download_f90",
                "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
@@ -113,6 +113,10 @@ class CaarLibrary:
                                               C.c_int, C.c_int, vp, vp, C.POINTER(_CaarOperatorScalars), vp]
         L.caar_preq_hydrostatic.argtypes = [C.POINTER(_CaarDims), C.c_int, vp, vp, vp, vp, C.c_double, vp, vp]
         L.caar_preq_omega_ps.argtypes = [C.POINTER(_CaarDims), C.c_int, vp, vp, vp, vp, vp]
+        L.caar_sphere_operator_host.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays), vp, C.c_int, C.c_int, vp, vp,
+                                                C.c_double]
+        L.caar_preq_hydrostatic_host.argtypes = [C.POINTER(_CaarDims), vp, vp, vp, vp, C.c_double, vp]
+        L.caar_preq_omega_ps_host.argtypes = [C.POINTER(_CaarDims), vp, vp, vp, vp]
         L.caar_reciprocal.argtypes = [vp, vp, C.c_longlong, vp]
         L.caar_kernel_name.argtypes = [C.c_int, C.c_int]
         L.caar_kernel_name.restype = C.c_char_p

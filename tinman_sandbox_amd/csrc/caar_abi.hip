@@ -34,9 +34,6 @@ hipError_t launch_stream_copy(double* dst, const double* src, size_t n_doubles, 
 hipError_t launch_stream_copy_tuned(double* dst, const double* src, size_t n_doubles, int variant, hipStream_t stream);
 int stream_copy_tuned_variants();
 const char* stream_copy_tuned_info(int v);
-hipError_t launch_sphere_operator(int np, int which, const double* in, double* out, const double* D,
-                                  const double* Dinv, const double* metdet, const double* rmetdet,
-                                  const double* dvv, int ie, int ne, int nlevels, double rrearth, hipStream_t s);
 hipError_t launch_reciprocal(const double* in, double* out, size_t n, hipStream_t s);
 struct OpArgs {  // caar_operators_ex.hip
   const double *D, *Dinv, *metdet, *rmetdet, *spheremp, *mp, *metinv, *tensorVisc, *vec_sph2cart;
@@ -375,6 +372,25 @@ static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const Caar
   k.p_top = p->hyai0 * p->ps0;  // P:84
 }
 
+// gradient / divergence / vorticity_sphere of the path (codes 0..2) on the CaarArrays geometry: the same kernel
+// as caar_sphere_operator_ex
+static int three_operators(int np, int which, const CaarArrays* dev, const double* dvv_dev, int e0, int ne, int nlevels,
+                           const double* in_dev, double* out_dev, double rrearth, void* stream) {
+  caar::OpArgs a = {};
+  a.D = dev->elem_D;
+  a.Dinv = dev->elem_Dinv;
+  a.metdet = dev->elem_metdet;
+  a.rmetdet = dev->elem_rmetdet;
+  a.dvv = dvv_dev;
+  a.in = in_dev;
+  a.out = out_dev;
+  a.e0 = e0;
+  a.ne = ne;
+  a.nlevels = nlevels;
+  a.rrearth = rrearth;
+  return (int)caar::launch_sphere_operator_ex(np, which, a, (hipStream_t)stream);
+}
+
 int caar_sphere_operator(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev, int which, int ie,
                          int nlevels, const double* in_dev, double* out_dev, double rrearth, void* stream) {
   if (!dims || !dev || !dvv_dev || !in_dev || !out_dev || which < 0 || which > 2 || nlevels < 0) return CAAR_EINVAL;
@@ -382,9 +398,7 @@ int caar_sphere_operator(const CaarDims* dims, const CaarArrays* dev, const doub
   if (dims->np != 4 && dims->np != 8) return CAAR_EUNSUPPORTED;
   if (!dev->elem_D || !dev->elem_Dinv || !dev->elem_metdet || !dev->elem_rmetdet) return CAAR_EINVAL;
   if ((((size_t)in_dev) | ((size_t)out_dev)) & 15) return CAAR_EINVAL;  // vector fields move as 16-byte (u, v) pairs
-  return (int)caar::launch_sphere_operator(dims->np, which, in_dev, out_dev, dev->elem_D, dev->elem_Dinv,
-                                           dev->elem_metdet, dev->elem_rmetdet, dvv_dev, ie, 1, nlevels, rrearth,
-                                           (hipStream_t)stream);
+  return three_operators(dims->np, which, dev, dvv_dev, ie, 1, nlevels, in_dev, out_dev, rrearth, stream);
 }
 
 int caar_sphere_operator_range(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev, int which, int e0,
@@ -395,9 +409,7 @@ int caar_sphere_operator_range(const CaarDims* dims, const CaarArrays* dev, cons
   if (dims->np != 4 && dims->np != 8) return CAAR_EUNSUPPORTED;
   if (!dev->elem_D || !dev->elem_Dinv || !dev->elem_metdet || !dev->elem_rmetdet) return CAAR_EINVAL;
   if ((((size_t)in_dev) | ((size_t)out_dev)) & 15) return CAAR_EINVAL;
-  return (int)caar::launch_sphere_operator(dims->np, which, in_dev, out_dev, dev->elem_D, dev->elem_Dinv,
-                                           dev->elem_metdet, dev->elem_rmetdet, dvv_dev, e0, e1 - e0, nlevels,
-                                           rrearth, (hipStream_t)stream);
+  return three_operators(dims->np, which, dev, dvv_dev, e0, e1 - e0, nlevels, in_dev, out_dev, rrearth, stream);
 }
 
 int caar_sphere_operator_ex(const CaarDims* dims, const CaarOperatorGeometry* geo, const double* dvv_dev, int which,
@@ -446,6 +458,113 @@ int caar_preq_omega_ps(const CaarDims* dims, int nelem, const double* p_dev, con
   if (dims->np < 1 || dims->nlev < 2) return CAAR_EINVAL;
   return (int)caar::launch_preq_omega_ps(dims->np, dims->nlev, nelem, p_dev, vgrad_p_dev, divdp_dev, omega_p_dev,
                                          (hipStream_t)stream);
+}
+
+// ---- host-pointer convenience forms of the operators (one element, synchronous) -------------------------
+namespace {
+struct HostOpScratch {
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  double* dev = nullptr;
+  size_t doubles = 0;
+  // returns a device area of at least n doubles (grown on demand), creating the stream on first use
+  hipError_t area(size_t n, double** out) {
+    hipError_t e = hipSetDevice(0);
+    if (e == hipSuccess && !stream) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    if (e == hipSuccess && doubles < n) {
+      if (dev) (void)hipFree(dev);
+      dev = nullptr;
+      doubles = 0;
+      e = hipMalloc((void**)&dev, sizeof(double) * n);
+      if (e == hipSuccess) doubles = n;
+    }
+    *out = dev;
+    return e;
+  }
+};
+HostOpScratch& host_op_scratch() {
+  static HostOpScratch* s = new HostOpScratch();  // never destroyed: no HIP calls from static destructors at exit
+  return *s;
+}
+}  // namespace
+
+int caar_sphere_operator_host(const CaarDims* dims, const CaarArrays* host, const double* dvv_host, int which, int ie,
+                              const double* in_host, double* out_host, double rrearth) {
+  if (!dims || !host || !dvv_host || !in_host || !out_host || which < 0 || which > 2) return CAAR_EINVAL;
+  if (ie < 0 || ie >= dims->num_elems) return CAAR_EINVAL;
+  if (dims->np != 4 && dims->np != 8) return CAAR_EUNSUPPORTED;
+  if (!host->elem_D || !host->elem_Dinv || !host->elem_metdet || !host->elem_rmetdet) return CAAR_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CAAR_ENODEVICE;
+  const size_t pp = (size_t)dims->np * dims->np, nin = which == 0 ? pp : 2 * pp, nout = which == 0 ? 2 * pp : pp;
+  HostOpScratch& s = host_op_scratch();
+  std::lock_guard<std::mutex> g(s.mu);
+  double* d = nullptr;
+  HIP_TRY(s.area(pp * 11 + nin + nout, &d));
+  double *dD = d, *dDinv = dD + pp * 4, *dmet = dDinv + pp * 4, *drmet = dmet + pp, *ddvv = drmet + pp, *din = ddvv + pp,
+         *dout = din + nin;
+  HIP_TRY(hipMemcpyAsync(dD, host->elem_D + (size_t)ie * pp * 4, sizeof(double) * pp * 4, hipMemcpyHostToDevice, s.stream));
+  HIP_TRY(hipMemcpyAsync(dDinv, host->elem_Dinv + (size_t)ie * pp * 4, sizeof(double) * pp * 4, hipMemcpyHostToDevice, s.stream));
+  HIP_TRY(hipMemcpyAsync(dmet, host->elem_metdet + (size_t)ie * pp, sizeof(double) * pp, hipMemcpyHostToDevice, s.stream));
+  HIP_TRY(hipMemcpyAsync(drmet, host->elem_rmetdet + (size_t)ie * pp, sizeof(double) * pp, hipMemcpyHostToDevice, s.stream));
+  HIP_TRY(hipMemcpyAsync(ddvv, dvv_host, sizeof(double) * pp, hipMemcpyHostToDevice, s.stream));
+  HIP_TRY(hipMemcpyAsync(din, in_host, sizeof(double) * nin, hipMemcpyHostToDevice, s.stream));
+  caar::OpArgs a = {};
+  a.D = dD;
+  a.Dinv = dDinv;
+  a.metdet = dmet;
+  a.rmetdet = drmet;
+  a.dvv = ddvv;
+  a.in = din;
+  a.out = dout;
+  a.e0 = 0;
+  a.ne = 1;
+  a.nlevels = 1;
+  a.rrearth = rrearth;
+  HIP_TRY(caar::launch_sphere_operator_ex(dims->np, which, a, s.stream));
+  HIP_TRY(hipMemcpyAsync(out_host, dout, sizeof(double) * nout, hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(hipStreamSynchronize(s.stream));
+  return CAAR_OK;
+}
+
+int caar_preq_hydrostatic_host(const CaarDims* dims, const double* phis, const double* T_v, const double* p, const double* dp,
+                               double Rgas, double* phi) {
+  if (!dims || !phis || !T_v || !p || !dp || !phi || dims->np < 1 || dims->nlev < 2) return CAAR_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CAAR_ENODEVICE;
+  const size_t pp = (size_t)dims->np * dims->np, blk = pp * dims->nlev;
+  HostOpScratch& s = host_op_scratch();
+  std::lock_guard<std::mutex> g(s.mu);
+  double* d = nullptr;
+  HIP_TRY(s.area(pp + 4 * blk, &d));
+  double *d_phis = d, *d_Tv = d_phis + pp, *d_p = d_Tv + blk, *d_dp = d_p + blk, *d_phi = d_dp + blk;
+  HIP_TRY(hipMemcpyAsync(d_phis, phis, sizeof(double) * pp, hipMemcpyHostToDevice, s.stream));
+  HIP_TRY(hipMemcpyAsync(d_Tv, T_v, sizeof(double) * blk, hipMemcpyHostToDevice, s.stream));
+  HIP_TRY(hipMemcpyAsync(d_p, p, sizeof(double) * blk, hipMemcpyHostToDevice, s.stream));
+  HIP_TRY(hipMemcpyAsync(d_dp, dp, sizeof(double) * blk, hipMemcpyHostToDevice, s.stream));
+  HIP_TRY(caar::launch_preq_hydrostatic(dims->np, dims->nlev, 1, d_phis, d_Tv, d_p, d_dp, Rgas, d_phi, s.stream));
+  HIP_TRY(hipMemcpyAsync(phi, d_phi, sizeof(double) * blk, hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(hipStreamSynchronize(s.stream));
+  return CAAR_OK;
+}
+
+int caar_preq_omega_ps_host(const CaarDims* dims, const double* p, const double* vgrad_p, const double* divdp, double* omega_p) {
+  if (!dims || !p || !vgrad_p || !divdp || !omega_p || dims->np < 1 || dims->nlev < 2) return CAAR_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CAAR_ENODEVICE;
+  const size_t pp = (size_t)dims->np * dims->np, blk = pp * dims->nlev;
+  HostOpScratch& s = host_op_scratch();
+  std::lock_guard<std::mutex> g(s.mu);
+  double* d = nullptr;
+  HIP_TRY(s.area(4 * blk, &d));
+  double *d_p = d, *d_vg = d_p + blk, *d_dd = d_vg + blk, *d_om = d_dd + blk;
+  HIP_TRY(hipMemcpyAsync(d_p, p, sizeof(double) * blk, hipMemcpyHostToDevice, s.stream));
+  HIP_TRY(hipMemcpyAsync(d_vg, vgrad_p, sizeof(double) * blk, hipMemcpyHostToDevice, s.stream));
+  HIP_TRY(hipMemcpyAsync(d_dd, divdp, sizeof(double) * blk, hipMemcpyHostToDevice, s.stream));
+  HIP_TRY(caar::launch_preq_omega_ps(dims->np, dims->nlev, 1, d_p, d_vg, d_dd, d_om, s.stream));
+  HIP_TRY(hipMemcpyAsync(omega_p, d_om, sizeof(double) * blk, hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(hipStreamSynchronize(s.stream));
+  return CAAR_OK;
 }
 
 int caar_reciprocal(const double* in_dev, double* out_dev, long long n, void* stream) {

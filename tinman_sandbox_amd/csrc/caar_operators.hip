@@ -1,11 +1,6 @@
-// caar_operators.hip — the three sphere operators as stand-alone device entry points.
-//
-// The reference exposes gradient_sphere / divergence_sphere / vorticity_sphere as functions
-// (cxx/pointers_only/sphere_operators.hpp:9-16: one np x np field of one element in, one
-// out).  In the fused CAAR kernels they are device functions without a launch of their
-// own; this file launches the SAME device functions (caar_np4_ops.h, caar_np8_ops.h) on a
-// batch of levels, so the operators can be driven and parity-tested exactly like the
-// reference's (caar_sphere_operator in include/caar.h).
+// caar_operators.hip — the two vertical integrals of the path as stand-alone device entry points
+// (caar_preq_hydrostatic / caar_preq_omega_ps) and the reciprocal numerics hook.  The sphere operators
+// as stand-alone launches (caar_sphere_operator, _range, _ex) live in caar_operators_ex.hip.
 #include <hip/hip_runtime.h>
 
 #include "caar_kernel_args.h"
@@ -13,91 +8,6 @@
 #include "caar_np8_ops.h"
 
 namespace caar {
-
-// which: 0 gradient (in [e][lev][np][np] -> out [e][lev][np][np][2]), 1 divergence, 2 vorticity
-// (in [e][lev][np][np][2] -> out [e][lev][np][np]), e = 0 .. ne-1 for elements ie0 .. ie0+ne-1.
-// One workgroup per element (grid-stride), its waves walk the element's 64-point tiles, so the
-// Dvv slices and the metric terms are fetched once per wave and element, not once per tile.
-__global__ __launch_bounds__(256) void sphere_operator_np4(int which, const double* __restrict__ in, double* __restrict__ out,
-                                    const double* __restrict__ D, const double* __restrict__ Dinv,
-                                    const double* __restrict__ metdet, const double* __restrict__ rmetdet,
-                                    const double* __restrict__ dvv, int ie0, int ne, int nlevels, double rrearth) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int pt = lane & 15, sub = lane >> 4;
-  const RowCoef c = make_row_coef(dvv, lane);
-  const int ntiles = (nlevels + 3) / 4;
-  for (int e = blockIdx.x; e < ne; e += gridDim.x) {
-    const size_t g = (size_t)(ie0 + e) * 16 + pt;
-    M22 Di, Dm;
-    Di.m00 = Dinv[g * 4 + 0]; Di.m01 = Dinv[g * 4 + 1]; Di.m10 = Dinv[g * 4 + 2]; Di.m11 = Dinv[g * 4 + 3];
-    Dm.m00 = D[g * 4 + 0]; Dm.m01 = D[g * 4 + 1]; Dm.m10 = D[g * 4 + 2]; Dm.m11 = D[g * 4 + 3];
-    const double md = metdet[g], rmd = rmetdet[g];
-    for (int t = w; t < ntiles; t += nw) {  // wave-uniform trip count
-      const int lev = t * 4 + sub;
-      const bool live = lev < nlevels;
-      const size_t o = ((size_t)e * nlevels + lev) * 16 + pt;
-      // every lane runs the DPP code (rows of a dead level just compute on zeros)
-      if (which == 0) {
-        const double s = live ? __builtin_nontemporal_load(in + o) : 0.0;
-        double g0, g1;
-        gradient_sphere(c, Di, rrearth, s, g0, g1);
-        dbl2 r;
-        r.x = g0;
-        r.y = g1;
-        if (live) __builtin_nontemporal_store(r, reinterpret_cast<dbl2*>(out) + o);
-      } else {
-        dbl2 uv;
-        uv.x = uv.y = 0.0;
-        if (live) uv = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(in) + o);
-        const double r = which == 1 ? divergence_sphere(c, Di, md, rmd, rrearth, uv.x, uv.y)
-                                    : vorticity_sphere(c, Dm, rmd, rrearth, uv.x, uv.y);
-        if (live) __builtin_nontemporal_store(r, out + o);
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void sphere_operator_np8(int which, const double* __restrict__ in, double* __restrict__ out,
-                                    const double* __restrict__ D, const double* __restrict__ Dinv,
-                                    const double* __restrict__ metdet, const double* __restrict__ rmetdet,
-                                    const double* __restrict__ dvv, int ie0, int ne, int nlevels, double rrearth) {
-  constexpr int NP = np8::NP;
-  __shared__ __attribute__((aligned(16))) double s_tile[4 * 64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  np8::Ctx c;
-  c.dvvT = nullptr;
-  c.tile = s_tile + w * 64;
-  c.a = lane >> 3;
-  c.b = lane & 7;
-#pragma unroll
-  for (int kk = 0; kk < NP; ++kk) {
-    c.ca[kk] = dvv[kk * NP + c.a];
-    c.cb[kk] = dvv[kk * NP + c.b];
-  }
-  for (int e = blockIdx.x; e < ne; e += gridDim.x) {
-    const size_t ie = (size_t)ie0 + e;
-    const size_t g = ie * 64 + lane;
-    const np8::M22 Di = np8::load_m22(Dinv + ie * 256, lane), Dm = np8::load_m22(D + ie * 256, lane);
-    const double md = metdet[g], rmd = rmetdet[g];
-    for (int lev = w; lev < nlevels; lev += nw) {  // wave-uniform
-      const size_t o = ((size_t)e * nlevels + lev) * 64 + lane;
-      np8::wave_lds_fence();  // the previous field's reads of the wave's tile are done
-      if (which == 0) {
-        double g0, g1;
-        np8::gradient_sphere(c, lane, Di, rrearth, __builtin_nontemporal_load(in + o), g0, g1);
-        dbl2 r;
-        r.x = g0;
-        r.y = g1;
-        __builtin_nontemporal_store(r, reinterpret_cast<dbl2*>(out) + o);
-      } else {
-        const dbl2 uv = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(in) + o);
-        const double r = which == 1 ? np8::divergence_sphere(c, lane, Di, md, rmd, rrearth, uv.x, uv.y)
-                                    : np8::vorticity_sphere(c, lane, Dm, rmd, rrearth, uv.x, uv.y);
-        __builtin_nontemporal_store(r, out + o);
-      }
-    }
-  }
-}
 
 // The two vertical integrals as functions of their own (reference: compute_and_apply_rhs.hpp:11-17 declares them
 // next to compute_and_apply_rhs; P:280-312 preq_hydrostatic, P:314-352 preq_omega_ps).  One thread per column, the
@@ -168,23 +78,6 @@ hipError_t launch_reciprocal(const double* in, double* out, size_t n, hipStream_
   if (n == 0) return hipSuccess;
   const size_t want = (n + 255) / 256;
   hipLaunchKernelGGL(reciprocal_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, in, out, n);
-  return hipGetLastError();
-}
-
-hipError_t launch_sphere_operator(int np, int which, const double* in, double* out, const double* D,
-                                  const double* Dinv, const double* metdet, const double* rmetdet,
-                                  const double* dvv, int ie, int ne, int nlevels, double rrearth, hipStream_t s) {
-  if (nlevels <= 0 || ne <= 0) return hipSuccess;
-  const unsigned grid = ne < 65536 ? ne : 65536;  // elements beyond that: grid-stride
-  if (np == 4) {
-    hipLaunchKernelGGL(sphere_operator_np4, dim3(grid), dim3(256), 0, s, which, in, out, D, Dinv, metdet, rmetdet,
-                       dvv, ie, ne, nlevels, rrearth);
-  } else if (np == 8) {
-    hipLaunchKernelGGL(sphere_operator_np8, dim3(grid), dim3(256), 0, s, which, in, out, D, Dinv, metdet,
-                       rmetdet, dvv, ie, ne, nlevels, rrearth);
-  } else {
-    return hipErrorInvalidValue;
-  }
   return hipGetLastError();
 }
 

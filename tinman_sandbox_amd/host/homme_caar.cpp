@@ -8,8 +8,11 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "caar.h"
 
@@ -66,7 +69,7 @@ CaarArrays host_arrays(const Arrays& a, int first_elem) {
 }
 
 CaarParams params_for(const TestData& d) {
-  CaarParams p;
+  CaarParams p = {};  // also the padding: caar_run_steps keys its cached graph on the values
   p.nets = d.control.nets;
   p.nete = d.control.nete;
   p.n0 = d.control.n0;
@@ -157,23 +160,100 @@ float DeviceSession::time_runs(const TestData& data, int reps) {
 // reads and writes them in place over PCIe (caar_map_host / caar_run_mapped): every input
 // byte crosses the link once, every output byte once, nothing is staged in HBM.  Still
 // PCIe-bound by construction: hosts that step in a loop should hold a DeviceSession.
-void compute_and_apply_rhs(TestData& data) {
-  static CaarHostMapping* mapping = nullptr;
-  static CaarArrays mapped;
-  static int mapped_elems = -1;
-  const int ne = data.control.nete > num_elems ? data.control.nete : num_elems;
-  const CaarArrays h = host_arrays(data.arrays);
-  if (!mapping || mapped_elems != ne || std::memcmp(&mapped, &h, sizeof(h)) != 0) {
-    if (mapping) (void)caar_unmap_host(mapping);  // the old arrays may already be freed: not an error here
-    mapping = nullptr;
+//
+// Re-entrant like the reference (HOMME's horizontal OpenMP calls it from several host threads on
+// disjoint [nets, nete) with their own Control copies): the page-lock registry below is guarded by a mutex and
+// every call holds a reference to the mapping it runs on, so a caller that triggers a re-mapping (other
+// arrays, other element count) cannot release it under a call still in flight; the launches themselves are
+// serialised inside caar_run_mapped.  The registry is keyed on the 16 array pointers and the element count: a
+// host that frees its arrays must call release_host_mapping() first (homme_data.cpp's cleanup_data does; the
+// reference's own main.cpp frees only at exit) — page locks on freed memory would otherwise be reused should
+// a later allocation land on the same addresses.
+namespace {
+struct Mapping {
+  CaarHostMapping* m = nullptr;
+  CaarArrays key;
+  int ne = -1;
+  ~Mapping() {
+    if (m) (void)caar_unmap_host(m);  // the arrays may already be freed: not an error here
+  }
+};
+std::mutex& registry_mutex() {
+  static std::mutex* mu = new std::mutex();  // never destroyed: no HIP calls from static destructors at exit
+  return *mu;
+}
+std::shared_ptr<Mapping>& registry() {
+  static std::shared_ptr<Mapping>* r = new std::shared_ptr<Mapping>();
+  return *r;
+}
+std::shared_ptr<Mapping> acquire_mapping(const CaarArrays& h, int ne) {
+  std::lock_guard<std::mutex> g(registry_mutex());
+  std::shared_ptr<Mapping>& cur = registry();
+  if (!cur || cur->ne != ne || std::memcmp(&cur->key, &h, sizeof(h)) != 0) {
+    cur.reset();  // unmapped now, or when the last call still running on it returns
     const CaarDims d = dims_for(ne);
     if (!caar_supported(d.np, d.nlev)) check(CAAR_EUNSUPPORTED, "caar_supported(np, nlev)");
-    check(caar_map_host(&mapping, &d, &h, 0), "caar_map_host");
-    mapped = h;
-    mapped_elems = ne;
+    std::shared_ptr<Mapping> m = std::make_shared<Mapping>();
+    check(caar_map_host(&m->m, &d, &h, 0), "caar_map_host");
+    m->key = h;
+    m->ne = ne;
+    cur = m;
   }
+  return cur;
+}
+}  // namespace
+
+void release_host_mapping() {
+  std::lock_guard<std::mutex> g(registry_mutex());
+  registry().reset();
+}
+
+void compute_and_apply_rhs(TestData& data) {
+  const int ne = data.control.nete > num_elems ? data.control.nete : num_elems;
+  const std::shared_ptr<Mapping> map = acquire_mapping(host_arrays(data.arrays), ne);
   const CaarParams p = params_for(data);
-  check(caar_run_mapped(mapping, &p), "caar_run_mapped");
+  check(caar_run_mapped(map->m, &p), "caar_run_mapped");
+}
+
+// ---------------------------------------------------------- the reference's operator functions
+// sphere_operators.hpp:9-16 and compute_and_apply_rhs.hpp:11-17 declare them next to the main routine: one np x np
+// field of one element (one column set of one element) in host memory in, one out.  Each call is a few hundred
+// bytes: upload, one launch of the device operator, download (caar_sphere_operator_host / caar_preq_*_host) —
+// latency, not bandwidth; hosts that care batch over levels and elements through the device-pointer entry points.
+// Thread-safe (the library keeps one device scratch area behind a mutex).
+namespace {
+void run_operator(int which, const real* in, const TestData& data, int ielem, real* out) {
+  const CaarDims d = dims_for(ielem + 1);
+  const CaarArrays h = host_arrays(data.arrays);
+  check(caar_sphere_operator_host(&d, &h, &data.deriv.Dvv[0][0], which, ielem, in, out, data.constants.rrearth),
+        "caar_sphere_operator_host");
+}
+}  // namespace
+
+// sphere_operators.hpp:9-10 (S:9-48)
+void gradient_sphere(const real* const s, const TestData& data, int ielem, real* const ds) {
+  run_operator(0, s, data, ielem, ds);
+}
+// sphere_operators.hpp:12-13 (S:50-89)
+void divergence_sphere(const real* const v, const TestData& data, int ielem, real* const div) {
+  run_operator(1, v, data, ielem, div);
+}
+// sphere_operators.hpp:15-16 (S:91-129)
+void vorticity_sphere(const real* const v, const TestData& data, int ielem, real* const vort) {
+  run_operator(2, v, data, ielem, vort);
+}
+
+// compute_and_apply_rhs.hpp:11-13 (P:280-312)
+void preq_hydrostatic(const real* const phis, const real* const T_v, const real* const p, const real* dp, real Rgas,
+                      real* const phi) {
+  const CaarDims d = dims_for(1);
+  check(caar_preq_hydrostatic_host(&d, phis, T_v, p, dp, Rgas, phi), "caar_preq_hydrostatic_host");
+}
+
+// compute_and_apply_rhs.hpp:15-17 (P:314-352)
+void preq_omega_ps(const real* const p, const real* const vgrad_p, const real* const divdp, real* const omega_p) {
+  const CaarDims d = dims_for(1);
+  check(caar_preq_omega_ps_host(&d, p, vgrad_p, divdp, omega_p), "caar_preq_omega_ps_host");
 }
 
 // P:353-370

@@ -26,6 +26,17 @@ struct CaarContext;
 namespace Homme {
 
 void compute_and_apply_rhs(TestData& data);
+// Releases the page locks compute_and_apply_rhs(TestData&) holds on the host arrays it ran on last.  Call it
+// before freeing those arrays (not part of the reference's surface: its callee holds no state).
+void release_host_mapping();
+// compute_and_apply_rhs.hpp:11-17
+void preq_hydrostatic(const real* const phis, const real* const T_v, const real* const p, const real* dp, real Rgas,
+                      real* const phi);
+void preq_omega_ps(const real* const p, const real* const vgrad_p, const real* const divdp, real* const omega_p);
+// sphere_operators.hpp:9-16
+void gradient_sphere(const real* const s, const TestData& data, int ielem, real* const ds);
+void divergence_sphere(const real* const v, const TestData& data, int ielem, real* const div);
+void vorticity_sphere(const real* const v, const TestData& data, int ielem, real* const vort);
 real compute_norm(const real* const field, int length);
 void print_results_2norm(const TestData& data);
 void dump_results_to_file(const TestData& data);

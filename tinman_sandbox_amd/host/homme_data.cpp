@@ -88,7 +88,10 @@ void Arrays::init_data() {
   }
 }
 
+void release_host_mapping();  // homme_caar.cpp
+
 void Arrays::cleanup_data() {
+  release_host_mapping();  // page locks compute_and_apply_rhs(TestData&) may hold on these arrays
   real** all[] = {&elem_D, &elem_Dinv, &elem_fcor, &elem_spheremp, &elem_metdet, &elem_rmetdet,
                   &elem_state_dp3d, &elem_state_v, &elem_state_T, &elem_state_phis, &elem_state_Qdp,
                   &elem_derived_eta_dot_dpdn, &elem_derived_omega_p, &elem_derived_phi,

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Bandwidth of the stand-alone sphere operators over a whole element range
-(caar_sphere_operator_range): bytes read + written over the HIP-event time."""
+"""Bandwidth of the stand-alone sphere operators over a whole element range: the three CAAR operators
+(caar_sphere_operator_range) and the neighbouring ones (caar_sphere_operator_ex): bytes read + written
+(field in + field out; the per-element geometry, read once per workgroup, is not counted) over the
+HIP-event time.  Log: profiles/r02/operator_bench.log"""
 import os
 import sys
 
@@ -9,23 +11,45 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinman_sandbox_amd as tsa  # noqa: E402
 
+
+def timed(fn, reps=20):
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        out = fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps, out
+
+
 for np_, nlev, E in ((4, 72, 10000), (4, 128, 12500), (8, 72, 20000)):
     data = tsa.TestData().init_data(E, np_, nlev, device="cuda")
     s = data.arrays["elem_state_T"][:, 0].contiguous()
     v = data.arrays["elem_state_v"][:, 0].contiguous()
-    row = []
-    for which, name, f in ((0, "gradient", s), (1, "divergence", v), (2, "vorticity", v)):
-        for _ in range(3):
-            tsa.sphere_operator_all(which, f, data)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(20):
-            out = tsa.sphere_operator_all(which, f, data)
-        b.record()
-        torch.cuda.synchronize()
-        ms = a.elapsed_time(b) / 20
-        byts = (f.numel() + out.numel()) * 8
-        row.append("%s %.3f ms %.0f GB/s" % (name, ms, byts / ms / 1e6))
-    print("np=%d nlev=%d E=%d: " % (np_, nlev, E) + " | ".join(row), flush=True)
-    del data
+    print("np=%d nlev=%d E=%d" % (np_, nlev, E), flush=True)
+    for which, name, f in ((0, "gradient_sphere", s), (1, "divergence_sphere", v), (2, "vorticity_sphere", v)):
+        ms, out = timed(lambda: tsa.sphere_operator_all(which, f, data))
+        print("  %-40s %7.3f ms  %6.0f GB/s" % (name + " (range)", ms, (f.numel() + out.numel()) * 8 / ms / 1e6), flush=True)
+    A = data.arrays
+    g = torch.Generator(device="cuda").manual_seed(1)
+
+    def rnd(*shape):
+        return torch.rand(shape, dtype=torch.float64, device="cuda", generator=g) + 0.5
+
+    geo = {"D": A["elem_D"], "Dinv": A["elem_Dinv"], "metdet": A["elem_metdet"], "rmetdet": A["elem_rmetdet"],
+           "spheremp": A["elem_spheremp"], "mp": rnd(E, np_, np_), "metinv": rnd(E, np_, np_, 2, 2),
+           "tensorVisc": rnd(E, np_, np_, 2, 2), "vec_sph2cart": rnd(E, np_, np_, 3, 2)}
+    dvv = data.dvv_device()
+    for name, (code, vin, vout) in tsa.SPHERE_OPERATORS.items():
+        if code < 3:
+            continue
+        f = v if vin else s
+        acc = torch.zeros((E, nlev, np_, np_) + ((2,) if vout else ()), dtype=torch.float64, device="cuda")
+        upd = name.endswith("_update")
+        ms, out = timed(lambda: tsa.sphere_operator_ex(name, f, geo, dvv, 1.5e-7, out=acc if upd else None))
+        byts = (f.numel() + out.numel() * (2 if upd else 1)) * 8
+        print("  %-40s %7.3f ms  %6.0f GB/s" % (name, ms, byts / ms / 1e6), flush=True)
+    del data, geo
     torch.cuda.empty_cache()
