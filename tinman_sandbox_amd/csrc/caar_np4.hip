@@ -84,8 +84,27 @@ enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, 
 // SNT: non-temporal (streaming) loads and stores; ANT: the same for the three read-modify-write
 // accumulators (derived_vn0, omega_p, eta_dot_dpdn), which a hybrid-policy kernel keeps in the
 // memory-side cache for part of the elements.
+// The workgroup's LDS, declared ONCE in the kernel and shared by the code paths instantiated inside it (the
+// hybrid cache policy compiles the element body twice; as function-local __shared__ arrays every buffer
+// existed twice: 17.4 KB instead of 8.7 KB at NLEV=72).
+template <int NLEV_T, int TPW, bool PERSIST, bool VADV, int DYNW>
+struct Np4Lds {
+  static constexpr int PP = 16;
+  static constexpr int NT_MAX = NLEV_T == 0 ? DYNW * TPW : (NLEV_T + 3) / 4;
+  static constexpr int COL = VADV ? (NT_MAX * 4 + 2) * PP : 1;
+  double dvv[16];
+  double geo_buf[PERSIST ? 2 : 1][208];  // G_SIZE; double-buffered across elements
+  double tot_dp[NT_MAX * PP];            // sum of dp over each tile
+  double tot_div[NT_MAX * PP];           // sum of divdp over each tile
+  double tot_ht[NT_MAX * PP];            // sum of Rgas*T_v*dp/p over each tile
+  // VADV: T, u, v at n0 of the whole column, [field][1 + level][pt] with a zero row above the top level and
+  // below the bottom one (and room for the dead rows of a ragged last tile)
+  double col[3][COL];
+  double hybi[VADV ? NT_MAX * 4 + 1 : 1];
+};
+
 template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW>
-__device__ __forceinline__ void caar_np4_element(const KernelArgs& k) {
+__device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW>& lds) {
   constexpr int PP = 16;               // GLL points per level
   constexpr bool DYN = NLEV_T == 0;
   constexpr int NT_MAX = DYN ? DYNW * TPW : (NLEV_T + 3) / 4;  // LDS sizing
@@ -99,16 +118,14 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k) {
   static_assert(!RAGGED || !PERSIST, "ragged level counts: non-persistent form only");
   static_assert(!VADV || (!PERSIST && !ETA_COND), "Eulerian branch: plain form only");
 
-  __shared__ double s_dvv[16];
-  __shared__ double s_geo_buf[PERSIST ? 2 : 1][G_SIZE];  // double-buffered across elements
-  __shared__ double s_tot_dp[NT_MAX * PP];   // sum of dp over each tile
-  __shared__ double s_tot_div[NT_MAX * PP];  // sum of divdp over each tile
-  __shared__ double s_tot_ht[NT_MAX * PP];   // sum of Rgas*T_v*dp/p over each tile
-  // VADV: T, u, v at n0 of the whole column, [field][1 + level][pt] with a zero row above the
-  // top level and below the bottom one (and room for the dead rows of a ragged last tile)
-  constexpr int COL = VADV ? (NT_MAX * 4 + 2) * PP : 1;
-  __shared__ double s_col[3][COL];
-  __shared__ double s_hybi[VADV ? NT_MAX * 4 + 1 : 1];
+  static_assert(G_SIZE == 208, "Np4Lds::geo_buf");
+  double* const s_dvv = lds.dvv;
+  auto& s_geo_buf = lds.geo_buf;
+  double* const s_tot_dp = lds.tot_dp;
+  double* const s_tot_div = lds.tot_div;
+  double* const s_tot_ht = lds.tot_ht;
+  auto& s_col = lds.col;
+  double* const s_hybi = lds.hybi;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -446,16 +463,17 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k) {
 //      kernel; the choice is uniform per workgroup.
 template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, bool PERSIST, bool ETA_COND, bool VADV = false, int DYNW = 8>
 __global__ __launch_bounds__(NLEV_T ? (NLEV_T + 3) / 4 / TPW * 64 : DYNW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
+  __shared__ Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW> lds;
   if constexpr (POL == 2) {
     static_assert(!PERSIST && !VADV, "hybrid cache policy: plain vertically-Lagrangian form only");
     const long long ie_s = element_of_block(k, blockIdx.x);
     if (ie_s < 0) return;
     if (element_is_cached(k, ie_s - k.nets))
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, false, PF, PERSIST, ETA_COND, VADV, DYNW>(k);
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, false, PF, PERSIST, ETA_COND, VADV, DYNW>(k, lds);
     else
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, true, PF, PERSIST, ETA_COND, VADV, DYNW>(k);
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, true, PF, PERSIST, ETA_COND, VADV, DYNW>(k, lds);
   } else {
-    caar_np4_element<NLEV_T, TPW, MINW, MOIST, POL == 1, POL == 1, PF, PERSIST, ETA_COND, VADV, DYNW>(k);
+    caar_np4_element<NLEV_T, TPW, MINW, MOIST, POL == 1, POL == 1, PF, PERSIST, ETA_COND, VADV, DYNW>(k, lds);
   }
 }
 
