@@ -17,8 +17,12 @@ program caar_f90_driver
   real(c_double), allocatable, target :: eta_dot_dpdn(:,:,:,:), omega_p(:,:,:,:), phi(:,:,:,:), pecnd(:,:,:,:)
   real(c_double), allocatable, target :: vn0(:,:,:,:,:)
   real(c_double), target :: Dvv_c(np*np)
-  real(c_double) :: Dvv(np,np), Dvv_init(np*np), nrm(3)
-  real(c_double) :: ii, jj, kk, iee
+  real(c_double) :: Dvv(np,np), nrm(3)
+  real(c_double) :: gi(np,np), gj(np,np), zk, ze
+  real, parameter :: dvv_single(np*np) = (/ -3.0, -0.80901699437494745, 0.30901699437494745, -0.5, &
+      4.0450849718747373, 0.0, -1.1180339887498949, 1.5450849718747370, &
+      -1.5450849718747370, 1.1180339887498949, 0.0, -4.0450849718747373, &
+      0.5, -0.30901699437494745, 0.80901699437494745, 3.0 /)
   type(caar_dims_t) :: dims
   type(caar_arrays_t) :: a
   type(caar_params_t) :: prm
@@ -43,51 +47,44 @@ program caar_f90_driver
   allocate(eta_dot_dpdn(np,np,nlev+1,nelemd), omega_p(np,np,nlev,nelemd), phi(np,np,nlev,nelemd), pecnd(np,np,nlev,nelemd))
   allocate(vn0(np,np,2,nlev,nelemd))
 
-  ! derivative matrix: default-real (single precision) literals widened to double, as in the
-  ! reference driver (main.F90:83-96) -- this is what its golden vectors were made with
-  Dvv_init(1:16) = (/ -3.0, -0.80901699437494745, 0.30901699437494745, -0.5, 4.0450849718747373, 0.0, &
-                      -1.1180339887498949, 1.5450849718747370, -1.5450849718747370, 1.1180339887498949, &
-                      0.0, -4.0450849718747373, 0.5, -0.30901699437494745, 0.80901699437494745, 3.0 /)
-  do j = 1, np
-    do i = 1, np
-      Dvv(i,j) = Dvv_init((j-1)*np + i)
-      Dvv_c((i-1)*np + j) = Dvv(i,j)
-    end do
-  end do
+  ! Derivative matrix: the reference driver's values are DEFAULT-REAL (single precision) literals widened to
+  ! double (main.F90:83-96) -- that is what its golden vectors were made with, so they stay single here.
+  ! reshape fills column-major: Dvv(i,j) = value((j-1)*np + i); the C ABI wants row-major Dvv[i][j].
+  Dvv = real(reshape(dvv_single, (/ np, np /)), c_double)
+  Dvv_c = reshape(transpose(Dvv), (/ np*np /))
 
+  ! Closed-form fields of the reference driver (main.F90:103-154), written as whole-level array expressions
+  ! over the GLL point indices gi(i,j) = i, gj(i,j) = j; every expression keeps the reference's operand order
+  ! (the state is compared with the reference's golden vectors digit for digit).
+  gi = spread((/ (real(i, c_double), i = 1, np) /), dim=2, ncopies=np)
+  gj = spread((/ (real(j, c_double), j = 1, np) /), dim=1, ncopies=np)
+  D = 0
+  Dinv = 0
   eta_dot_dpdn = 0
   Qdp = 0
+  vn0 = 1.0
+  pecnd = 1.0
   do ie = 1, nelemd
-    iee = ie
-    do j = 1, np
-      jj = j
-      do i = 1, np
-        ii = i
-        fcor(i,j,ie) = sin(ii + jj)
-        metdet(i,j,ie) = ii*jj
-        rmetdet(i,j,ie) = 1.0d0/metdet(i,j,ie)
-        spheremp(i,j,ie) = 2*ii
-        phis(i,j,ie) = i + j
-        D(i,j,:,:,ie) = 0
-        D(i,j,1,1,ie) = 1.0
-        D(i,j,2,2,ie) = 2.0
-        Dinv(i,j,:,:,ie) = 0
-        Dinv(i,j,1,1,ie) = 1.0
-        Dinv(i,j,2,2,ie) = 0.5
-        do k = 1, nlev
-          kk = k
-          phi(i,j,k,ie) = cos(ii + 3*jj) + kk
-          vn0(i,j,1:2,k,ie) = 1.0
-          pecnd(i,j,k,ie) = 1.0
-          omega_p(i,j,k,ie) = jj*jj
-          do tl = 1, timelevels
-            dp3d(i,j,k,tl,ie) = 10*kk + iee + ii + jj + tl
-            v(i,j,1,k,tl,ie) = 1.0 + kk/2 + ii + jj + iee/5 + tl*2.0
-            v(i,j,2,k,tl,ie) = 1.0 + kk/2 + ii + jj + iee/5 + tl*3.0
-            T(i,j,k,tl,ie) = 1000 - kk - ii - jj + iee/10 + tl
-          end do
-          Qdp(i,j,k,1,1,ie) = 1.0 + sin(ii*jj*kk)
-        end do
+    ze = ie
+    fcor(:,:,ie) = sin(gi + gj)
+    metdet(:,:,ie) = gi*gj
+    rmetdet(:,:,ie) = 1.0d0/metdet(:,:,ie)
+    spheremp(:,:,ie) = 2*gi
+    phis(:,:,ie) = gi + gj
+    D(:,:,1,1,ie) = 1.0
+    D(:,:,2,2,ie) = 2.0
+    Dinv(:,:,1,1,ie) = 1.0
+    Dinv(:,:,2,2,ie) = 0.5
+    do k = 1, nlev
+      zk = k
+      phi(:,:,k,ie) = cos(gi + 3*gj) + zk
+      omega_p(:,:,k,ie) = gj*gj
+      Qdp(:,:,k,1,1,ie) = 1.0 + sin(gi*gj*zk)
+      do tl = 1, timelevels
+        dp3d(:,:,k,tl,ie) = 10*zk + ze + gi + gj + tl
+        v(:,:,1,k,tl,ie) = 1.0 + zk/2 + gi + gj + ze/5 + tl*2.0
+        v(:,:,2,k,tl,ie) = 1.0 + zk/2 + gi + gj + ze/5 + tl*3.0
+        T(:,:,k,tl,ie) = 1000 - zk - gi - gj + ze/10 + tl
       end do
     end do
   end do
