@@ -50,6 +50,9 @@ def parse():
                     help="also time 20 launches one by one (roofline.kernel_ms_isolated_*)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short extra measurements of BASELINE.json configs[3] and [4]")
+    ap.add_argument("--no-spinup", action="store_true",
+                    help="skip the untimed device spin-up before the W warmup steps: the timed steps then run on a "
+                         "device that is still ramping up (fresh process: clocks, TLBs, cache window; ~25 ms)")
     ap.add_argument("--cpu-seconds", type=float, default=1.5,
                     help="target wall seconds per host thread for the CPU baseline sample")
     return ap.parse_args()
@@ -220,6 +223,30 @@ TRAFFIC_SOURCE = ("static: profiles/hbm_traffic.json (rocprofv3 --pmc passes com
                   "not measured in this run; L2-side counters: Infinity-Cache hits are counted as traffic)")
 
 
+def spin_up(tsa, torch, data, stream, dev, block=20, max_blocks=40, tol=0.003):
+    """Untimed launches of the same step until its time per launch is stable.  A fresh process does not run at its
+    steady rate at once: the first ~60 launches (~25 ms) of a 10 000-element step ramp from ~70 % to the steady 74-77 %
+    of peak on this pool (power state, TLBs, the cache window filling; profiles/r02/cold_probe.log).  A time-stepping
+    host runs in the steady state; W = 5 warmup steps (2 ms) do not reach it.  Returns the per-launch times of the
+    blocks (ms): [0] is the cold figure."""
+    blocks = []
+    for _ in range(max_blocks):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(block):
+            tsa.compute_and_apply_rhs(data, stream)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        blocks.append(e0.elapsed_time(e1) / block)
+        if len(blocks) >= 3 and abs(blocks[-1] - blocks[-2]) <= tol * blocks[-1] and abs(blocks[-2] - blocks[-3]) <= tol * blocks[-2]:
+            break
+    return blocks
+
+
+def balg_of(tsa, args):
+    return tsa.algorithmic_bytes(args.np_, args.nlev)
+
+
 def time_launches(tsa, torch, data, stream, dev, steps, warmup):
     for _ in range(warmup):
         tsa.compute_and_apply_rhs(data, stream)
@@ -280,6 +307,11 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # first-use cost (code object load, first-touch) and, unless --no-spinup, the ramp to the steady state
+    tsa.compute_and_apply_rhs(data, stream)
+    torch.cuda.synchronize(dev)
+    spin = [] if args.no_spinup else spin_up(tsa, torch, data, stream, dev)
+
     for _ in range(args.warmup):
         tsa.compute_and_apply_rhs(data, stream)
     torch.cuda.synchronize(dev)
@@ -315,6 +347,19 @@ def main():
         kernel_ms_streaming = time_launches(tsa, torch, data, stream, dev, args.steps, 3)
         lib.caar_select_variant(args.np_, args.nlev, 0)
         (kernel_ms_streaming,) = sharding.max_over_ranks([kernel_ms_streaming], dist, reduce_dev)
+
+    # The steady rate depends on WHERE the driver placed the arrays in HBM: allocations of the same process differ by a
+    # reproducible 3-5 % (two levels, e.g. 73.5 / 76.5 % of peak; not TLB misses, not the cache window, not the relative
+    # offsets of the arrays: DESIGN.md section 5, profiles/r02/placement_*.log).  `value` is measured on the first allocation,
+    # whatever it got; here the same step on three more allocations of this process, so the line shows the spread.
+    placement = []
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        others = [tsa.TestData().init_data(mine, args.np_, args.nlev, device=dev, first_elem=nets) for _ in range(3)]
+        for d in [data] + others:
+            time_launches(tsa, torch, d, stream, dev, 20, 40)
+            placement.append(balg_of(tsa, args) * mine / (time_launches(tsa, torch, d, stream, dev, 20, 0) * 1e-3) / 1e9)
+        del others
+        torch.cuda.empty_cache()
 
     # per-launch spread (median and min), outside the timed region: one event pair per
     # launch.  These intervals come out ~4 % shorter than the back-to-back average above: a launch
@@ -357,6 +402,13 @@ def main():
                              if args.np_ == 4 and window else "every access streams from/to HBM",
             "kernel_ms_isolated_min": per_launch[0] if per_launch else None,
             "kernel_ms_isolated_median": per_launch[len(per_launch) // 2] if per_launch else None,
+            # the untimed spin-up before the W warmup steps (see spin_up): how long it took to reach the steady
+            # rate, and what the first block of launches of this process ran at (the cold figure)
+            # the same step on [the timed allocation, three further allocations] (GB/s), after the timed region
+            "placement_spread_achieved": placement or None,
+            "spinup": {"launches": 20 * len(spin), "kernel_ms_first_20_launches": spin[0],
+                       "achieved_first_20_launches": per_launch_bytes / (spin[0] * 1e-3) / 1e9,
+                       "kernel_ms_last_20_launches": spin[-1]} if spin else None,
         }
         if kernel_ms_streaming is not None:
             a0 = per_launch_bytes / (kernel_ms_streaming * 1e-3) / 1e9
@@ -398,9 +450,9 @@ def main():
             #  * configs[4] NP=8, 20 000 elements
             del data
             torch.cuda.empty_cache()
-            out["other_configs"] = [measure_config(tsa, torch, dev, 4, 72, 12500, 20, 3),
-                                    measure_config(tsa, torch, dev, 4, 128, 12500, 20, 3),
-                                    measure_config(tsa, torch, dev, 8, 72, 20000, 10, 2)]
+            out["other_configs"] = [measure_config(tsa, torch, dev, 4, 72, 12500, 20, 20),
+                                    measure_config(tsa, torch, dev, 4, 128, 12500, 20, 10),
+                                    measure_config(tsa, torch, dev, 8, 72, 20000, 10, 4)]
         if world == 1 and not args.no_other_configs:
             roof["measured_on_this_box"] = measured_ceilings(tsa, torch, dev, args.np_, args.nlev, mine)
         if world == 1 and not args.no_cpu_baseline:
