@@ -139,15 +139,8 @@ def measure_config(tsa, torch, dev, np_, nlev, elems, steps, warmup):
     """Kernel-only measurement of one more configuration (HIP events on the launch stream)."""
     data = tsa.TestData().init_data(elems, np_, nlev, device=dev)
     stream = torch.cuda.current_stream(dev)
-    for _ in range(warmup):
-        tsa.compute_and_apply_rhs(data, stream)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(steps):
-        tsa.compute_and_apply_rhs(data, stream)
-    e1.record(stream)
-    torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / steps
+    # two timed blocks, the faster one: see placement_spread about occasional stalls
+    ms = min(time_launches(tsa, torch, data, stream, dev, steps, warmup), time_launches(tsa, torch, data, stream, dev, steps, 0))
     balg = tsa.algorithmic_bytes(np_, nlev)
     gbs = balg * elems / (ms * 1e-3) / 1e9
     del data
@@ -259,6 +252,25 @@ def time_launches(tsa, torch, data, stream, dev, steps, warmup):
     return e0.elapsed_time(e1) / steps
 
 
+def placement_spread(tsa, torch, args, data, dev, stream, mine, nets):
+    """The steady rate depends on WHERE the driver placed the arrays in HBM: allocations of the same process differ by a
+    reproducible 3-5 % (two levels, e.g. 73.5 / 76.5 % of peak; not TLB misses, not the cache window, not the relative
+    offsets of the arrays: DESIGN.md section 5, profiles/r02/placement_probes.log), and allocations made after a lot of
+    allocate/free traffic tend to get the slower level.  `value` is measured on the first allocation of the process,
+    whatever it got; this repeats the same step on it and on three more allocations, so the line shows the spread."""
+    out = []
+    others = [tsa.TestData().init_data(mine, args.np_, args.nlev, device=dev, first_elem=nets) for _ in range(3)]
+    for d in [data] + others:
+        time_launches(tsa, torch, d, stream, dev, 20, 40)
+        # best of three blocks: a block is occasionally hit by a stall of tens of ms (the driver wiping memory freed
+        # earlier in the run), which says nothing about the placement
+        ms = min(time_launches(tsa, torch, d, stream, dev, 20, 0) for _ in range(3))
+        out.append(balg_of(tsa, args) * mine / (ms * 1e-3) / 1e9)
+    del others
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -348,19 +360,6 @@ def main():
         lib.caar_select_variant(args.np_, args.nlev, 0)
         (kernel_ms_streaming,) = sharding.max_over_ranks([kernel_ms_streaming], dist, reduce_dev)
 
-    # The steady rate depends on WHERE the driver placed the arrays in HBM: allocations of the same process differ by a
-    # reproducible 3-5 % (two levels, e.g. 73.5 / 76.5 % of peak; not TLB misses, not the cache window, not the relative
-    # offsets of the arrays: DESIGN.md section 5, profiles/r02/placement_*.log).  `value` is measured on the first allocation,
-    # whatever it got; here the same step on three more allocations of this process, so the line shows the spread.
-    placement = []
-    if rank == 0 and world == 1 and not args.no_other_configs:
-        others = [tsa.TestData().init_data(mine, args.np_, args.nlev, device=dev, first_elem=nets) for _ in range(3)]
-        for d in [data] + others:
-            time_launches(tsa, torch, d, stream, dev, 20, 40)
-            placement.append(balg_of(tsa, args) * mine / (time_launches(tsa, torch, d, stream, dev, 20, 0) * 1e-3) / 1e9)
-        del others
-        torch.cuda.empty_cache()
-
     # per-launch spread (median and min), outside the timed region: one event pair per
     # launch.  These intervals come out ~4 % shorter than the back-to-back average above: a launch
     # that starts on an idle chip does not share HBM with the write-back of its predecessor's
@@ -404,8 +403,9 @@ def main():
             "kernel_ms_isolated_median": per_launch[len(per_launch) // 2] if per_launch else None,
             # the untimed spin-up before the W warmup steps (see spin_up): how long it took to reach the steady
             # rate, and what the first block of launches of this process ran at (the cold figure)
-            # the same step on [the timed allocation, three further allocations] (GB/s), after the timed region
-            "placement_spread_achieved": placement or None,
+            # which dispatches of this kernel on this grid are the timed ones (0-based, in launch order), so that a
+            # rocprofv3 kernel trace of this command can be cut to the timed region (tools/trace_stats.py --window)
+            "timed_dispatches": [1 + 20 * len(spin) + args.warmup, 1 + 20 * len(spin) + args.warmup + args.steps],
             "spinup": {"launches": 20 * len(spin), "kernel_ms_first_20_launches": spin[0],
                        "achieved_first_20_launches": per_launch_bytes / (spin[0] * 1e-3) / 1e9,
                        "kernel_ms_last_20_launches": spin[-1]} if spin else None,
@@ -448,12 +448,15 @@ def main():
             #  * 12 500 elements NP=4 NLEV=72 = one GPU's share of configs[2] (what --gpus 8 runs per GPU)
             #  * configs[3] NP=4 NLEV=128, one GPU's share of 100 000 elements
             #  * configs[4] NP=8, 20 000 elements
-            del data
-            torch.cuda.empty_cache()
+            # (the headline arrays stay allocated: freeing and re-allocating them would change what placement_spread sees)
             out["other_configs"] = [measure_config(tsa, torch, dev, 4, 72, 12500, 20, 20),
                                     measure_config(tsa, torch, dev, 4, 128, 12500, 20, 10),
                                     measure_config(tsa, torch, dev, 8, 72, 20000, 10, 4)]
         if world == 1 and not args.no_other_configs:
+            # the same step on [the timed allocation, three further allocations] (GB/s)
+            roof["placement_spread_achieved"] = placement_spread(tsa, torch, args, data, dev, stream, mine, nets)
+            del data
+            torch.cuda.empty_cache()
             roof["measured_on_this_box"] = measured_ceilings(tsa, torch, dev, args.np_, args.nlev, mine)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.np_, args.nlev, args.cpu_seconds)

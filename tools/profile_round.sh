@@ -17,7 +17,8 @@ echo "[profile] bench.py under rocprofv3 --kernel-trace --stats"
 rm -rf "$OUT/bench_trace"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_trace" -- python3 "$ROOT/bench.py" > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err"
 cp "$(find "$OUT/bench_trace" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_kernel_stats.csv"
-python3 "$ROOT/tools/trace_stats.py" "$OUT/bench_trace" > "$OUT/bench_kernel_stats_by_grid.csv"
+python3 "$ROOT/tools/trace_stats.py" "$OUT/bench_trace" "--window=$OUT/bench_under_rocprof.json" > "$OUT/bench_kernel_stats_by_grid.csv"
+tail -1 "$OUT/bench_kernel_stats_by_grid.csv" | cut -c1-260
 head -4 "$OUT/bench_kernel_stats_by_grid.csv" | cut -c1-200
 fi
 if [[ $PARTS != *pmc* ]]; then exit 0; fi
