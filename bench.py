@@ -264,10 +264,18 @@ def placement_spread(tsa, torch, args, data, dev, stream, mine, nets):
     """The steady rate depends on WHERE the driver placed the arrays in HBM: allocations of the same process differ by a
     reproducible 3-5 % (two levels, e.g. 73.5 / 76.5 % of peak; not TLB misses, not the cache window, not the relative
     offsets of the arrays: DESIGN.md section 5, profiles/r02/placement_probes.log), and allocations made after a lot of
-    allocate/free traffic tend to get the slower level.  `value` is measured on the first allocation of the process,
-    whatever it got; this repeats the same step on it and on three more allocations, so the line shows the spread."""
+    allocate/free traffic tend to get the slower level.  The library's allocator (caar_arrays_alloc, used by
+    TestData.init_data) spreads every array over the address classes by construction.  `value` is measured on the first
+    allocation of the process; this repeats the same step on it, on two more allocations of that kind and on one set of
+    plain torch allocations (last entry), so the line shows what placement is worth in this process."""
     out = []
-    others = [tsa.TestData().init_data(mine, args.np_, args.nlev, device=dev, first_elem=nets) for _ in range(3)]
+    others = [tsa.TestData().init_data(mine, args.np_, args.nlev, device=dev, first_elem=nets) for _ in range(2)]
+    # ... and on torch's own sixteen allocations (what round 1 measured on), last in the list
+    os.environ["CAAR_PLACEMENT"] = "torch"
+    try:
+        others.append(tsa.TestData().init_data(mine, args.np_, args.nlev, device=dev, first_elem=nets))
+    finally:
+        del os.environ["CAAR_PLACEMENT"]
     for d in [data] + others:
         time_launches(tsa, torch, d, stream, dev, 20, 40)
         # best of three blocks: a block is occasionally hit by a stall of tens of ms (the driver wiping memory freed
@@ -447,6 +455,9 @@ def main():
                             "reference closed-form element arrays" % (args.np_, args.nlev, mine, total_elems),
                 "parallelism": "element-sharded x%d, no collectives" % world,
                 "kernel": lib.caar_kernel_name(args.np_, args.nlev).decode(),
+                "array_placement": ("caar_arrays_alloc: 64 MiB physical chunks sampled from a temporary pool, every array spread "
+                                    "over the device's address classes (DESIGN.md section 5)"
+                                    if data.arrays.arena is not None and data.arrays.arena.spread() else "plain allocations"),
             },
             "hbm_gbs_algorithmic_job": total_elems * args.steps * balg / wall_max / 1e9,
             "roofline": roof,
@@ -460,7 +471,7 @@ def main():
             out["other_configs"] = [measure_config(4, 72, 12500, 20, 5), measure_config(4, 128, 12500, 20, 5),
                                     measure_config(8, 72, 20000, 10, 3)]
         if world == 1 and not args.no_other_configs:
-            # the same step on [the timed allocation, three further allocations] (GB/s)
+            # the same step on [the timed allocation, two more placed allocations, plain torch allocations] (GB/s)
             roof["placement_spread_achieved"] = placement_spread(tsa, torch, args, data, dev, stream, mine, nets)
             del data
             torch.cuda.empty_cache()

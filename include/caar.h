@@ -302,6 +302,20 @@ const char *caar_stream_copy_tuned_info(int variant);
 int caar_traffic_skeleton(const CaarDims *dims, const CaarArrays *dev, const CaarParams *params,
                           int variant, void *stream);
 
+/* ---- device arrays placed for bandwidth ----------------------------------------------------
+ * Allocates the 16 element arrays for `dims` on HIP device `device` and returns their DEVICE pointers in *out_dev.
+ * Where the arrays lie in HBM matters on MI355X: device memory falls into a few large address classes and the path runs
+ * 3-5 % faster when its traffic is split over several of them than when all arrays lie in one (DESIGN.md section 5
+ * "Placement").  So the arrays are backed, through HIP virtual memory management, by 64 MiB physical chunks sampled
+ * evenly from a large temporary pool (up to 128 GiB or 60 % of the free memory; CAAR_PLACEMENT_POOL_GIB), every array
+ * contiguous in virtual memory and at least 2 MiB-aligned.  Data sets below 256 MiB, CAAR_PLACEMENT=malloc in the
+ * environment, or a failing VMM route fall back to one hipMalloc per array.  caar_create allocates this way too.
+ * caar_arrays_placement: 1 if the arena is chunk-backed (and the pool size / chunk size it used), 0 if plain. */
+typedef struct CaarArena CaarArena;
+int caar_arrays_alloc(CaarArena **arena, const CaarDims *dims, int device, CaarArrays *out_dev);
+int caar_arrays_free(CaarArena *arena);
+int caar_arrays_placement(const CaarArena *arena, long long *pool_chunks, long long *chunk_bytes);
+
 /* ---- context API: the library owns the device copies ---------------------------
  * What Homme::compute_and_apply_rhs(TestData&) needs when TestData lives in host
  * memory (Arrays::init_data, data_structures.cpp:14-31). */

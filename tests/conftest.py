@@ -9,6 +9,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# The placed allocator (caar_arrays_alloc) samples its physical chunks from a temporary pool; re-creating a 128 GiB pool
+# costs ~4 s per allocation once the process has released memory before (the driver wipes it).  The tests exercise the
+# same code path with a small pool.
+os.environ.setdefault("CAAR_PLACEMENT_POOL_GIB", "16")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -313,3 +313,91 @@ def test_cache_window_changes_nothing_but_speed():
         assert lib.caar_set_cache_window(-1) != 0
     finally:
         lib.caar_set_cache_window(192 << 20)
+
+
+def test_arrays_placed_for_bandwidth_compute_the_same(oracle, monkeypatch):
+    """caar_arrays_alloc (include/caar.h; DESIGN.md section 5 "Placement"): arrays backed by physical chunks spread over the
+    device's address classes through HIP virtual memory management.  Same results bit for bit as torch-allocated
+    arrays, chunk-backed from 256 MiB on, plain hipMalloc below that or on request, memory returned when released."""
+    import gc
+    E = 2000  # 372 MB of arrays
+    spread = tsa.TestData().init_data(E, 4, 72, device="cuda")
+    assert spread.arrays.arena is not None and spread.arrays.arena.spread()
+    for n in tsa.ARRAY_NAMES:
+        assert spread.arrays[n].data_ptr() % (2 << 20) == 0, n      # every array starts on a chunk boundary of the range
+    monkeypatch.setenv("CAAR_PLACEMENT", "torch")
+    plain = tsa.TestData().init_data(E, 4, 72, device="cuda")
+    assert plain.arrays.arena is None
+    monkeypatch.delenv("CAAR_PLACEMENT")
+    for n in tsa.ARRAY_NAMES:
+        assert torch.equal(spread.arrays[n], plain.arrays[n]), n     # same initial data
+    for _ in range(2):
+        tsa.compute_and_apply_rhs(spread)
+        tsa.compute_and_apply_rhs(plain)
+    torch.cuda.synchronize()
+    for n in tsa.ARRAY_NAMES:
+        assert torch.equal(spread.arrays[n], plain.arrays[n]), n
+    # against the oracle on a few elements
+    arrs = {n: spread.arrays[n][:3].cpu().numpy().copy() for n in tsa.ARRAY_NAMES}
+    want = oracle.init_arrays(4, 72, 1, 3, 3)
+    sc = po.default_scalars(72)
+    for _ in range(2):
+        oracle.compute_and_apply_rhs(want, oracle.dvv_np4(False), sc)
+    for n in cases.OUTPUT_NAMES:
+        assert cases.scaled_err(arrs[n], want[n]) <= 1e-12, n
+    # small data sets and CAAR_PLACEMENT=malloc: plain allocations through the same entry point
+    small = tsa.TestData().init_data(8, 4, 72, device="cuda")
+    assert small.arrays.arena is not None and not small.arrays.arena.spread()
+    monkeypatch.setenv("CAAR_PLACEMENT", "malloc")
+    forced = tsa.TestData().init_data(E, 4, 72, device="cuda")
+    assert forced.arrays.arena is not None and not forced.arrays.arena.spread()
+    monkeypatch.delenv("CAAR_PLACEMENT")
+    # released memory comes back (tensors keep the arena alive until the last one is gone)
+    del spread, plain, small, forced, arrs
+    gc.collect()
+    torch.cuda.empty_cache()
+    def cycle():
+        d = tsa.TestData().init_data(E, 4, 72, device="cuda")
+        keep = d.arrays["elem_state_T"]
+        del d
+        gc.collect()
+        assert keep.sum().item() != 0.0   # still valid: the view holds the arena
+        del keep
+        gc.collect()
+        torch.cuda.empty_cache()
+        return torch.cuda.mem_get_info()[0]
+    cycle()
+    free1 = cycle()
+    for _ in range(4):
+        free2 = cycle()
+    assert free1 - free2 < (64 << 20), (free1, free2)   # no physical memory lost per allocate / release cycle
+
+
+def test_context_api_allocates_through_the_placed_allocator(oracle):
+    """caar_create backs its arrays the same way; results as before."""
+    import ctypes as C
+    from tinman_sandbox_amd import caar as m
+    L = tsa.library()
+    E = 1500
+    arrs = oracle.init_arrays(4, 72, 1, 3, E)
+    want = cases.copy_arrays(arrs)
+    sc = po.default_scalars(72)
+    Dvv = oracle.dvv_np4(False)
+    sc2 = dict(sc, nets=0, nete=4)
+    oracle.compute_and_apply_rhs(want, Dvv, sc2)
+    dims = m._CaarDims(4, 72, 1, 3, E)
+    ctx = C.c_void_p()
+    L.check(L.lib.caar_create(C.byref(ctx), C.byref(dims), 0), "create")
+    host = m._CaarArrays(*[arrs[n].ctypes.data_as(m._dp) for n in tsa.ARRAY_NAMES])
+    L.check(L.lib.caar_upload(ctx, C.byref(host), 0, E), "upload")
+    dvv = np.ascontiguousarray(Dvv)
+    prm = m._CaarParams(0, 4, sc["n0"], sc["np1"], sc["nm1"], sc["qn0"], sc["dt2"], sc["rrearth"], sc["eta_ave_w"],
+                        sc["Rwater_vapor"], sc["Rgas"], sc["kappa"], sc["ps0"], float(sc["hyai"][0]),
+                        dvv.ctypes.data_as(m._dp), 1, None, None)
+    L.check(L.lib.caar_run(ctx, C.byref(prm)), "run")
+    L.check(L.lib.caar_download(ctx, C.byref(host), 0, E, 0), "download")
+    L.check(L.lib.caar_sync(ctx), "sync")
+    L.lib.caar_destroy(ctx)
+    for n in cases.OUTPUT_NAMES:
+        assert cases.scaled_err(arrs[n][:4], want[n][:4]) <= 1e-12, n
+        assert np.array_equal(arrs[n][4:], want[n][4:]), n

@@ -81,7 +81,7 @@ class CaarLibrary:
     SYMBOLS = ("caar_supported", "caar_abi_version", "caar_device_count", "caar_strerror", "caar_array_len",
                "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator", "caar_sphere_operator_range", "caar_sphere_operator_ex", "caar_preq_hydrostatic", "caar_preq_omega_ps", "caar_sphere_operator_host", "caar_preq_hydrostatic_host", "caar_preq_omega_ps_host", "caar_reciprocal",
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
-               "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_selected_variant", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_stream_copy_tuned", "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_create", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_download_f90",
+               "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_selected_variant", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_stream_copy_tuned", "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_arrays_alloc", "caar_arrays_free", "caar_arrays_placement", "caar_create", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_download_f90",
                "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
                "caar_time_runs", "caar_run_steps", "caar_map_host", "caar_run_mapped", "caar_unmap_host")
 
@@ -138,6 +138,9 @@ class CaarLibrary:
         L.caar_stream_copy_tuned_info.restype = C.c_char_p
         L.caar_traffic_skeleton.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays),
                                             C.POINTER(_CaarParams), C.c_int, vp]
+        L.caar_arrays_alloc.argtypes = [C.POINTER(vp), C.POINTER(_CaarDims), C.c_int, C.POINTER(_CaarArrays)]
+        L.caar_arrays_free.argtypes = [vp]
+        L.caar_arrays_placement.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.caar_create.argtypes = [C.POINTER(vp), C.POINTER(_CaarDims), C.c_int]
         L.caar_destroy.argtypes = [vp]
         L.caar_destroy.restype = None
@@ -210,6 +213,36 @@ def shard_range(num_elems, rank, world_size):
     return nets, min(nets + per, num_elems)
 
 
+class _Arena:
+    """Device memory from caar_arrays_alloc (placed for bandwidth, DESIGN.md section 5 "Placement"), freed when the last
+    tensor that views it is gone."""
+
+    def __init__(self, dims, device_index):
+        self.lib = library()
+        self.handle = C.c_void_p()
+        self.ptrs = _CaarArrays()
+        self.lib.check(self.lib.lib.caar_arrays_alloc(C.byref(self.handle), C.byref(dims), device_index, C.byref(self.ptrs)),
+                       "caar_arrays_alloc")
+
+    def spread(self):
+        return self.lib.lib.caar_arrays_placement(self.handle, None, None) == 1
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.lib.lib.caar_arrays_free(self.handle)
+            self.handle = None
+
+
+class _ArenaView:
+    """One array of an _Arena through the CUDA array interface (torch.as_tensor shares the memory and keeps this object,
+    hence the arena, alive)."""
+
+    def __init__(self, arena, ptr, shape):
+        self.arena = arena
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False), "version": 2,
+                                         "strides": None}
+
+
 class ElementArrays:
     """The 16 element arrays (Homme::Arrays) as torch float64 tensors on one device."""
 
@@ -218,6 +251,18 @@ class ElementArrays:
         self.qsize_d, self.timelevels = qsize_d, timelevels
         self.device = torch.device(device)
         shapes = array_shapes(np_, nlev, qsize_d, timelevels, num_elems)
+        self.arena = None
+        if tensors is None and self.device.type == "cuda" and os.environ.get("CAAR_PLACEMENT", "") != "torch":
+            # the library's allocator: every array spread over the device's address classes (include/caar.h
+            # caar_arrays_alloc); CAAR_PLACEMENT=torch keeps torch's own sixteen allocations
+            idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            with torch.cuda.device(idx):
+                self.arena = _Arena(_CaarDims(np_, nlev, qsize_d, timelevels, num_elems), idx)
+                ptrs = [C.cast(getattr(self.arena.ptrs, f), C.c_void_p).value for f, _ in _CaarArrays._fields_]
+                tensors = {}
+                for n, p in zip(ARRAY_NAMES, ptrs):
+                    t = torch.as_tensor(_ArenaView(self.arena, p, shapes[n]), device=torch.device("cuda", idx))
+                    tensors[n] = t.zero_()
         if tensors is None:
             tensors = {n: torch.zeros(s, dtype=torch.float64, device=self.device) for n, s in shapes.items()}
         for n in ARRAY_NAMES:

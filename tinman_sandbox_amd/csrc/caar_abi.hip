@@ -166,6 +166,7 @@ struct CaarContext {
   int device;
   hipStream_t stream;
   CaarArrays dev;       // device pointers
+  CaarArena* arena;     // what owns them (caar_arrays_alloc)
   caar::HostConstants consts;  // Dvv and hybi on the device
   double* norms_dev;    // 3 * num_elems
   double* stage_dev;    // staging for Fortran-ordered host arrays (largest array), lazily allocated
@@ -662,8 +663,13 @@ int caar_create(CaarContext** out, const CaarDims* dims, int device) {
   c->dims = *dims;
   c->device = device;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  for (int i = 0; e == hipSuccess && i < CAAR_NUM_ARRAYS; ++i)
-    e = hipMalloc((void**)array_slot(&c->dev, i), sizeof(double) * caar_array_len(dims, i));
+  if (e == hipSuccess) {
+    const int rc = caar_arrays_alloc(&c->arena, dims, device, &c->dev);  // placed for bandwidth (caar_alloc.hip)
+    if (rc != CAAR_OK) {
+      caar_destroy(c);
+      return rc;
+    }
+  }
   if (e == hipSuccess) e = c->consts.create(dims->nlev);
   if (e == hipSuccess) e = hipMalloc((void**)&c->norms_dev, sizeof(double) * 3 * dims->num_elems);
   if (e != hipSuccess) {
@@ -678,8 +684,7 @@ void caar_destroy(CaarContext* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (int i = 0; i < CAAR_NUM_ARRAYS; ++i)
-    if (*array_slot(&c->dev, i)) (void)hipFree(*array_slot(&c->dev, i));
+  if (c->arena) (void)caar_arrays_free(c->arena);
   c->consts.destroy();
   if (c->norms_dev) (void)hipFree(c->norms_dev);
   if (c->stage_dev) (void)hipFree(c->stage_dev);
