@@ -1,5 +1,9 @@
+"""Allocate / release / allocate placed arenas of different sizes and check the results against the golden outputs each time:
+shows the ROCm 7.2 defect worked around in csrc/caar_alloc.hip (a virtual range that is freed and reserved again keeps its old
+GPU translations) when run against a build that frees its ranges, and nothing with the committed build."""
 import sys, os, gc
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, ctypes as C
 import cases
 from oracle import pyoracle as po
