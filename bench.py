@@ -201,7 +201,7 @@ def measured_ceilings(tsa, torch, dev, np_, nlev, elems):
     if np_ == 4:
         data = tsa.TestData().init_data(elems, np_, nlev, device=dev)
         dims, ptrs, prm = data.arrays.dims(), data.arrays.pointers(), data.params()
-        t = timed(lambda: L.check(L.lib.caar_traffic_skeleton(C.byref(dims), C.byref(ptrs), C.byref(prm), 8,
+        t = timed(lambda: L.check(L.lib.caar_traffic_skeleton(C.byref(dims), C.byref(ptrs), C.byref(prm), 22 if nlev == 72 else 2,
                                                               C.c_void_p(st.cuda_stream)), "skeleton"))
         out["traffic_skeleton_GBs"] = tsa.algorithmic_bytes(np_, nlev) * elems / t / 1e9
         del data

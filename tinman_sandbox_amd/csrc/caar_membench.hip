@@ -308,6 +308,7 @@ hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, i
       case 18: hipLaunchKernelGGL((traffic_skeleton_np4<72, 1, 1, 1, true, 16, 6>), dim3(num_elems * 3), dim3(384), 0, s, k); break;
       case 19: hipLaunchKernelGGL((traffic_skeleton_np4<72, 2, 1, 1, true, 16, 3>), dim3(num_elems * 3), dim3(192), 0, s, k); break;
       case 20: hipLaunchKernelGGL((traffic_skeleton_np4<72, 1, 1, 1, false, 16, 1>), dim3(num_elems * 18), dim3(64), 0, s, k); break;
+      case 22: skel<72, 6, 1, 1, true>(k, num_elems, s); break;   // the default kernel's launch shape (3 waves x 6 tiles), nt
       case 13: hipLaunchKernelGGL((traffic_skeleton_np4_w16<72, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(576), 0, s, k); break;
       case 14: hipLaunchKernelGGL((traffic_skeleton_np4_w16<72, 0>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(576), 0, s, k); break;
       default: return hipErrorInvalidValue;

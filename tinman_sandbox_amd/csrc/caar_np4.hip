@@ -523,6 +523,8 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
+    {"caar_np4_kernel<72, 6, 1, true, 2, 0, false, false, false, 8>", "3 waves x 6 tiles (two workgroups per CU), hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<72, 6, 1, 2, 0, 0, false, 3, 2, 0>},
+    {"caar_np4_kernel<72, 6, 1, true, 1, 0, false, false, false, 8>", "3 waves x 6 tiles (two workgroups per CU), nt (all streaming), update loads one tile ahead", launch_np4<72, 6, 1, true, 0, 0, false, 3, 2, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 2, 1, false, false, false, 8>", "9 waves x 2 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<72, 2, 1, 2, 1, 0, false, 3, 2, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, false, false, 8>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, true, false, 8>", "9 waves x 2 tiles, nt; eta_dot_dpdn stored only where its bits change (skips the no-op write-back: NOT the contract traffic)", launch_np4<72, 2, 1, true, 1, 0, true, 3, 2, 0>},
@@ -531,7 +533,9 @@ KernelVariant kNp4Nlev72[] = {
     {"caar_np4_kernel<72, 2, 1, true, 1, 0, false, false, false, 8>", "9 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<72, 2, 1, true, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 0, 1, false, false, false, 8>", "9 waves x 2 tiles, default cache policy", launch_np4<72, 2, 1, false, 1>},
     {"caar_np4_kernel<72, 3, 2, true, 1, 1, false, false, false, 8>", "6 waves x 3 tiles, nt, update loads before the last barrier", launch_np4<72, 3, 2, true, 1>},
-    {"caar_np4_kernel<72, 6, 1, true, 1, 0, false, false, false, 8>", "3 waves x 6 tiles, nt", launch_np4<72, 6, 1, true, 0>},
+    {"caar_np4_kernel<72, 3, 2, true, 2, 1, false, false, false, 8>", "6 waves x 3 tiles, hybrid cache policy, update loads before the last barrier", launch_np4<72, 3, 2, 2, 1>},
+    {"caar_np4_kernel<72, 3, 2, true, 2, 0, false, false, false, 8>", "6 waves x 3 tiles, room for 2 waves/SIMD, hybrid cache policy, update loads one tile ahead", launch_np4<72, 3, 2, 2, 0>},
+    {"caar_np4_kernel<72, 2, 1, true, 2, 0, false, false, false, 8>", "9 waves x 2 tiles, hybrid cache policy, update loads one tile ahead", launch_np4<72, 2, 1, 2, 0>},
 };
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
@@ -542,6 +546,8 @@ KernelVariant kNp4Nlev128[] = {
     {"caar_np4_kernel<128, 4, 2, true, 0, 1, false, false, false, 8>", "8 waves x 4 tiles, default cache policy", launch_np4<128, 4, 2, false, 1>},
     {"caar_np4_kernel<128, 8, 1, true, 1, 0, false, false, false, 8>", "4 waves x 8 tiles, nt", launch_np4<128, 8, 1, true, 0>},
     {"caar_np4_kernel<128, 2, 4, true, 1, 0, false, false, false, 8>", "16 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<128, 2, 4, true, 0, 0, false, 8, 1, 0>},
+    {"caar_np4_kernel<128, 4, 2, true, 2, 0, false, false, false, 8>", "8 waves x 4 tiles, hybrid cache policy, update loads one tile ahead", launch_np4<128, 4, 2, 2, 0>},
+    {"caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8>", "4 waves x 8 tiles, room for 2 waves/SIMD (two workgroups per CU), hybrid cache policy", launch_np4<128, 8, 2, 2, 0>},
 };
 int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 
