@@ -575,5 +575,5 @@ def test_element_counts_and_workgroup_mappings(oracle, np_, nlev):
                         assert np.array_equal(g[:nets], a[:nets]) and np.array_equal(g[nete:], a[nete:]), \
                             (chunked, v, nets, nete, n)
     finally:
-        lib.caar_set_xcd_chunked(0)
+        lib.caar_set_xcd_chunked(-1)
         lib.caar_select_variant(np_, nlev, 0)

@@ -141,7 +141,7 @@ struct HostConstants {
 // Process-wide tuning knobs.  Atomics, read once per launch into a LaunchChoice, so setters may race
 // with launches on other threads (HOMME's horizontal OpenMP calls the routine from several host
 // threads): every launch sees one consistent set of values.
-static std::atomic<int> g_xcd_chunked{0};  // workgroup -> element mapping, see element_of_block()
+static std::atomic<int> g_xcd_chunked{-1};  // workgroup -> element mapping, see element_of_block(); -1: what the variant prefers
 // bytes of element data the hybrid cache policy keeps in the memory-side cache (0: none, all streaming);
 // default = best of a 0..320 MB sweep at NLEV 72 and 128 (the cache holds 256 MB, shared with everything else)
 static std::atomic<long long> g_cache_window{CAAR_CACHE_WINDOW_DEFAULT};
@@ -156,6 +156,7 @@ static LaunchChoice launch_choice(const Config* cfg) {
   LaunchChoice c;
   c.variant = cfg ? cfg->selected.load(std::memory_order_relaxed) : 0;
   c.xcd_chunked = g_xcd_chunked.load(std::memory_order_relaxed);
+  if (c.xcd_chunked < 0) c.xcd_chunked = cfg && cfg->variants[c.variant].prefers_xcd_chunked ? 1 : 0;
   c.cache_window = g_cache_window.load(std::memory_order_relaxed);
   return c;
 }
@@ -236,7 +237,7 @@ int caar_set_cache_window(long long bytes) {
 long long caar_get_cache_window(void) { return g_cache_window.load(); }
 
 int caar_set_xcd_chunked(int on) {
-  g_xcd_chunked.store(on ? 1 : 0);
+  g_xcd_chunked.store(on < 0 ? -1 : (on ? 1 : 0));
   return CAAR_OK;
 }
 

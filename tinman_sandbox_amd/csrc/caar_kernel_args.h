@@ -103,6 +103,7 @@ struct KernelVariant {
   const char* kernel;  // demangled kernel name as rocprofv3 prints it
   const char* what;
   hipError_t (*launch)(const KernelArgs&, int num_elems, hipStream_t stream);
+  bool prefers_xcd_chunked = false;  // measured faster with each XCD on a contiguous eighth of the element range
 };
 
 }  // namespace caar

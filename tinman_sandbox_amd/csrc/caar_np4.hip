@@ -523,7 +523,7 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
-    {"caar_np4_kernel<72, 6, 1, true, 2, 0, false, false, false, 8>", "3 waves x 6 tiles (two workgroups per CU), hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<72, 6, 1, 2, 0, 0, false, 3, 2, 0>},
+    {"caar_np4_kernel<72, 6, 1, true, 2, 0, false, false, false, 8>", "3 waves x 6 tiles (two workgroups per CU), hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<72, 6, 1, 2, 0, 0, false, 3, 2, 0>, true},
     {"caar_np4_kernel<72, 6, 1, true, 1, 0, false, false, false, 8>", "3 waves x 6 tiles (two workgroups per CU), nt (all streaming), update loads one tile ahead", launch_np4<72, 6, 1, true, 0, 0, false, 3, 2, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 2, 1, false, false, false, 8>", "9 waves x 2 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<72, 2, 1, 2, 1, 0, false, 3, 2, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, false, false, 8>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},

@@ -69,11 +69,11 @@ def main():
                 err = float((out[n] - ref[n]).abs().max() / ref[n].abs().max().clamp_min(1e-300))
                 assert err <= 1e-12, (v, n, err)
 
-    def run_variant(v, chunked=0):
+    def run_variant(v, chunked=-1):
         L.check(lib.caar_select_variant(a.np_, a.nlev, v), "select")
         lib.caar_set_xcd_chunked(chunked)
         t = time_ms(lambda: tsa.compute_and_apply_rhs(data, stream), a.reps, stream)
-        lib.caar_set_xcd_chunked(0)
+        lib.caar_set_xcd_chunked(-1)
         return t
 
     # memory ceilings
@@ -106,6 +106,7 @@ def main():
                 times[key].append(run_variant(key[1]))
             elif key[0] == "roundrobin":
                 times[key].append(run_variant(key[1], 1))
+                times.setdefault(("dealt", key[1]), []).append(run_variant(key[1], 0))
             elif key[0] == "copy":
                 times[key].append(copy(key[1]))
             else:
@@ -125,6 +126,9 @@ def main():
             print("variant %d  %8.4f ms  %7.3f M upd/s  %7.1f GB/s alg  %5.1f%% of 8TB/s  [min %.4f max %.4f]  %s" % (
                 v, ms, a.elems / ms / 1e3, gbs, gbs / 80.0, min(ts), max(ts), name))
             results["variant%d" % v] = dict(ms=ms, gbs=gbs, what=name)
+        elif key[0] == "dealt":
+            gbs = balg * a.elems / (ms * 1e-3) / 1e9
+            print("variant %d elements dealt round-robin over the XCDs  %8.4f ms  %7.1f GB/s alg  %5.1f%% of 8TB/s" % (key[1], ms, gbs, gbs / 80.0))
         elif key[0] == "roundrobin":
             gbs = balg * a.elems / (ms * 1e-3) / 1e9
             print("variant %d XCD-chunked elements  %8.4f ms  %7.1f GB/s alg  %5.1f%% of 8TB/s" % (key[1], ms, gbs, gbs / 80.0))
