@@ -87,7 +87,7 @@ enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, 
 // The workgroup's LDS, declared ONCE in the kernel and shared by the code paths instantiated inside it (the
 // hybrid cache policy compiles the element body twice; as function-local __shared__ arrays every buffer
 // existed twice: 17.4 KB instead of 8.7 KB at NLEV=72).
-template <int NLEV_T, int TPW, bool PERSIST, bool VADV, int DYNW>
+template <int NLEV_T, int TPW, bool PERSIST, bool VADV, int DYNW, int PARK = 0>
 struct Np4Lds {
   static constexpr int PP = 16;
   static constexpr int NT_MAX = NLEV_T == 0 ? DYNW * TPW : (NLEV_T + 3) / 4;
@@ -101,10 +101,17 @@ struct Np4Lds {
   // below the bottom one (and room for the dead rows of a ragged last tile)
   double col[3][COL];
   double hybi[VADV ? NT_MAX * 4 + 1 : 1];
+  // PARK (bit mask): p (1), the divdp prefix (2), the in-tile hydrostatic suffix (4), divdp (8), T_v (16) of every point
+  // wait here between the phases ([slot][tile * 64 + lane]; each lane re-reads only what it wrote)
+  static constexpr int NPARK = (PARK & 1) + ((PARK >> 1) & 1) + ((PARK >> 2) & 1) + ((PARK >> 3) & 1) + ((PARK >> 4) & 1);
+  double park[NPARK ? NPARK : 1][NPARK ? NT_MAX * 64 : 1];
 };
 
-template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW>
-__device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW>& lds) {
+// PARK: the five per-point values that live from the scans to the last phase (p, divdp prefix, hydrostatic in-tile suffix,
+// divdp, T_v) wait in LDS instead of registers (10 VGPRs per tile): lets a fat shape (few waves x many tiles) stay within
+// 256 registers, i.e. two workgroups per CU, where the level count makes the tiles-per-wave large (NLEV=128: 4 waves x 8).
+template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW, int PARK = 0>
+__device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW, PARK>& lds) {
   constexpr int PP = 16;               // GLL points per level
   constexpr bool DYN = NLEV_T == 0;
   constexpr int NT_MAX = DYN ? DYNW * TPW : (NLEV_T + 3) / 4;  // LDS sizing
@@ -117,6 +124,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   static_assert(DYN || NT_MAX % TPW == 0, "tile decomposition");
   static_assert(!RAGGED || !PERSIST, "ragged level counts: non-persistent form only");
   static_assert(!VADV || (!PERSIST && !ETA_COND), "Eulerian branch: plain form only");
+  static_assert(PARK == 0 || (!RAGGED && !PERSIST && !VADV), "PARK: plain vertically-Lagrangian form, level count a multiple of 4");
 
   static_assert(G_SIZE == 208, "Np4Lds::geo_buf");
   double* const s_dvv = lds.dvv;
@@ -321,6 +329,14 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         if (sub == 0) s_tot_ht[t * PP + pt] = in_ht;
         base_dp += s_tot_dp[t * PP + pt];
         base_div += s_tot_div[t * PP + pt];
+        if constexpr (PARK != 0) {
+          constexpr int S1 = PARK & 1, S2 = S1 + ((PARK >> 1) & 1), S3 = S2 + ((PARK >> 2) & 1), S4 = S3 + ((PARK >> 3) & 1);
+          if constexpr (PARK & 1) lds.park[0][t * 64 + lane] = p[r];
+          if constexpr (PARK & 2) lds.park[S1][t * 64 + lane] = suml[r];
+          if constexpr (PARK & 4) lds.park[S2][t * 64 + lane] = ex_ht[r];
+          if constexpr (PARK & 8) lds.park[S3][t * 64 + lane] = divdp[r];
+          if constexpr (PARK & 16) lds.park[S4][t * 64 + lane] = Tv[r];
+        }
       }
       if (VADV) {
         for (int t2 = w * TPW + TPW; t2 < NT; ++t2) base_div += s_tot_div[t2 * PP + pt];
@@ -371,16 +387,35 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       const unsigned off = r * 64 + ulane;
       TileIn nxt = cur;
       if (r > 0) nxt = PF ? pre[r - 1] : load_tile(r - 1);
+      double p_r, suml_r, exht_r, divdp_r, Tv_r;  // this tile's scan results (registers, or parked in LDS)
+      if constexpr (PARK == 0) {
+        p_r = p[r];
+        suml_r = suml[r];
+        exht_r = ex_ht[r];
+        divdp_r = divdp[r];
+        Tv_r = Tv[r];
+      } else {
+        const volatile double* pk = &lds.park[0][0] + t * 64 + lane;  // volatile: must not be forwarded through registers
+        constexpr int Q = NT_MAX * 64;
+        constexpr int S1 = PARK & 1, S2 = S1 + ((PARK >> 1) & 1), S3 = S2 + ((PARK >> 2) & 1), S4 = S3 + ((PARK >> 3) & 1);
+        if constexpr (PARK & 1) p_r = pk[0]; else p_r = p[r];
+        if constexpr (PARK & 2) suml_r = pk[Q * S1]; else suml_r = suml[r];
+        if constexpr (PARK & 4) exht_r = pk[Q * S2]; else exht_r = ex_ht[r];
+        if constexpr (PARK & 8) divdp_r = pk[Q * S3]; else divdp_r = divdp[r];
+        if constexpr (PARK & 16) Tv_r = pk[Q * S4]; else Tv_r = Tv[r];
+      }
+      double rp_r;
+      if constexpr (PARK & 1) rp_r = recip(p_r); else rp_r = rp[r];
 
-      const double ht = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);         // same expression as in phase 2
-      const double phi = (phis + (below + ex_ht[r])) + 0.5 * ht;    // P:303,309
+      const double ht = (k.Rgas * Tv_r) * (dp[r] * rp_r);         // same expression as in phase 2
+      const double phi = (phis + (below + exht_r)) + 0.5 * ht;    // P:303,309
       below += s_tot_ht[t * PP + pt];
 
       double gp0, gp1;
-      gradient_sphere(c, Dinv, rrearth, p[r], gp0, gp1);            // P:103
+      gradient_sphere(c, Dinv, rrearth, p_r, gp0, gp1);            // P:103
       const double vgrad_p = u[r] * gp0 + v[r] * gp1;               // P:111
-      const double ckk = 0.5 * rp[r], ckl = rp[r];                  // P:333-334 (ckl = 2*ckk)
-      const double om = vgrad_p * rp[r] - ckl * suml[r] - ckk * divdp[r];  // P:325,336,348
+      const double ckk = 0.5 * rp_r, ckl = rp_r;                  // P:333-334 (ckl = 2*ckk)
+      const double om = vgrad_p * rp_r - ckl * suml_r - ckk * divdp_r;  // P:325,336,348
       const double vort = vorticity_sphere(c, Dm, rmetdet, rrearth, u[r], v[r]);  // P:122
 
       const double Ephi = 0.5 * (u[r] * u[r] + v[r] * v[r]) + phi + cur.pec;  // P:196
@@ -388,18 +423,18 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       gradient_sphere(c, Dinv, rrearth, T[r], gT0, gT1);            // P:200
       const double vgrad_T = u[r] * gT0 + v[r] * gT1;               // P:209
       gradient_sphere(c, Dinv, rrearth, Ephi, gE0, gE1);            // P:213
-      const double gpterm = Tv[r] * rp[r];                          // P:219
+      const double gpterm = Tv_r * rp_r;                          // P:219
       const double glnps1 = k.Rgas * gpterm * gp0;                  // P:221
       const double glnps2 = k.Rgas * gpterm * gp1;                  // P:222
       double vtens1 = v[r] * (fcor + vort) - gE0 - glnps1;          // P:227 (v_vadv == 0)
       double vtens2 = -u[r] * (fcor + vort) - gE1 - glnps2;         // P:228
-      double ttens = -vgrad_T + k.kappa * Tv[r] * om;               // P:230 (T_vadv == 0)
+      double ttens = -vgrad_T + k.kappa * Tv_r * om;               // P:230 (T_vadv == 0)
       double eta_lo = 0.0, eta_hi = 0.0;  // interface mass flux above / below this level
       if (VADV) {
         const int lev = t * 4 + sub;
         // X:238-254: eta_dot(k+1) = hybi(k+1)*sdot_sum - sum_{l<=k} divdp(l); 0 at the top and the surface
-        eta_lo = lev == 0 ? 0.0 : s_hybi[lev] * sdot_sum - suml[r];
-        eta_hi = lev >= NLEV - 1 ? 0.0 : s_hybi[lev + 1] * sdot_sum - (suml[r] + divdp[r]);
+        eta_lo = lev == 0 ? 0.0 : s_hybi[lev] * sdot_sum - suml_r;
+        eta_hi = lev >= NLEV - 1 ? 0.0 : s_hybi[lev + 1] * sdot_sum - (suml_r + divdp_r);
         const double half_rdp = 0.5 * recip(dp[r]);                 // X:118
         const double facp = half_rdp * eta_hi, facm = half_rdp * eta_lo;   // CaarFunctor.hpp:526-527
         const int ci = PP + t * 64 + lane;
@@ -409,7 +444,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         const double v_vadv = facp * (s_col[2][ci + PP] - v[r]) + facm * (v[r] - s_col[2][ci - PP]);
         vtens1 = -u_vadv + v[r] * (fcor + vort) - gE0 - glnps1;     // X:326-328
         vtens2 = -v_vadv - u[r] * (fcor + vort) - gE1 - glnps2;     // X:332-334
-        ttens = -T_vadv - vgrad_T + k.kappa * Tv[r] * om;           // X:338
+        ttens = -T_vadv - vgrad_T + k.kappa * Tv_r * om;           // X:338
       }
 
       if (RAGGED && !live_row(r)) {
@@ -421,8 +456,8 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);              // P:252
       stream_store<SNT>(v_np1 + off, vo);
       stream_store<SNT>(T_np1 + off, spheremp * (cur.Tnm1 + k.dt2 * ttens));        // P:253
-      if (VADV) stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * (divdp[r] + eta_hi - eta_lo)));  // X:515-517
-      else stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * divdp[r]));   // P:254
+      if (VADV) stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * (divdp_r + eta_hi - eta_lo)));  // X:515-517
+      else stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * divdp_r));   // P:254
       stream_store<SNT>(phi_out + off, phi);                                        // P:294,303,309
       stream_store<ANT>(omega_p + off, cur.om + k.eta_ave_w * om);                  // P:173
       dbl2 vn;
@@ -461,19 +496,19 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
 //      survive the rest of the launch, and the next call on the same arrays (a time-stepping host, the
 //      reference's driver loop) finds them there instead of in HBM.  Both code paths live in the
 //      kernel; the choice is uniform per workgroup.
-template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, bool PERSIST, bool ETA_COND, bool VADV = false, int DYNW = 8>
+template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, bool PERSIST, bool ETA_COND, bool VADV = false, int DYNW = 8, int PARK = 0>
 __global__ __launch_bounds__(NLEV_T ? (NLEV_T + 3) / 4 / TPW * 64 : DYNW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
-  __shared__ Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW> lds;
+  __shared__ Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW, PARK> lds;
   if constexpr (POL == 2) {
     static_assert(!PERSIST && !VADV, "hybrid cache policy: plain vertically-Lagrangian form only");
     const long long ie_s = element_of_block(k, blockIdx.x);
     if (ie_s < 0) return;
     if (element_is_cached(k, ie_s - k.nets))
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, false, PF, PERSIST, ETA_COND, VADV, DYNW>(k, lds);
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, false, PF, PERSIST, ETA_COND, VADV, DYNW, PARK>(k, lds);
     else
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, true, PF, PERSIST, ETA_COND, VADV, DYNW>(k, lds);
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, true, PF, PERSIST, ETA_COND, VADV, DYNW, PARK>(k, lds);
   } else {
-    caar_np4_element<NLEV_T, TPW, MINW, MOIST, POL == 1, POL == 1, PF, PERSIST, ETA_COND, VADV, DYNW>(k, lds);
+    caar_np4_element<NLEV_T, TPW, MINW, MOIST, POL == 1, POL == 1, PF, PERSIST, ETA_COND, VADV, DYNW, PARK>(k, lds);
   }
 }
 
@@ -492,7 +527,7 @@ static int cu_count() {
 // VTPW/VMINW/VPF: the launch shape of the Eulerian (rsplit == 0) form, which holds more live
 // values per level and wants fewer, fatter waves (tools/eulerian_bench.py).
 template <int NLEV, int TPW, int MINW, int POL, int PF = 0, int PERSIST_WG_PER_CU = 0, bool ETA_COND = false,
-          int VTPW = TPW, int VMINW = MINW, int VPF = PF>
+          int VTPW = TPW, int VMINW = MINW, int VPF = PF, int PARK = 0>
 static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = (NLEV + 3) / 4 / TPW * 64;
   constexpr bool PERSIST = PERSIST_WG_PER_CU > 0;
@@ -511,9 +546,9 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
     return hipGetLastError();
   }
   if (k.qn0 >= 0)
-    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true, POL, PF, PERSIST, ETA_COND>), dim3(grid), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, true, POL, PF, PERSIST, ETA_COND, false, 8, PARK>), dim3(grid), dim3(THREADS), 0, stream, k);
   else  // dry branch (P:128-139): the Qdp block is never touched
-    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false, POL, PF, PERSIST, ETA_COND>), dim3(grid), dim3(THREADS), 0, stream, k);
+    hipLaunchKernelGGL((caar_np4_kernel<NLEV, TPW, MINW, false, POL, PF, PERSIST, ETA_COND, false, 8, PARK>), dim3(grid), dim3(THREADS), 0, stream, k);
   return hipGetLastError();
 }
 
@@ -536,10 +571,13 @@ KernelVariant kNp4Nlev72[] = {
     {"caar_np4_kernel<72, 3, 2, true, 2, 1, false, false, false, 8>", "6 waves x 3 tiles, hybrid cache policy, update loads before the last barrier", launch_np4<72, 3, 2, 2, 1>},
     {"caar_np4_kernel<72, 3, 2, true, 2, 0, false, false, false, 8>", "6 waves x 3 tiles, room for 2 waves/SIMD, hybrid cache policy, update loads one tile ahead", launch_np4<72, 3, 2, 2, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 2, 0, false, false, false, 8>", "9 waves x 2 tiles, hybrid cache policy, update loads one tile ahead", launch_np4<72, 2, 1, 2, 0>},
+    {"caar_np4_kernel<72, 6, 1, true, 2, 0, false, false, false, 8, 31>", "3 waves x 6 tiles, scan results parked in LDS, hybrid cache policy", launch_np4<72, 6, 1, 2, 0, 0, false, 3, 2, 0, 31>},
 };
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
+    {"caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS between the phases, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<128, 8, 2, 2, 0, 0, false, 8, 1, 0, 27>},
+    {"caar_np4_kernel<128, 8, 2, true, 1, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS, nt (all streaming), update loads one tile ahead", launch_np4<128, 8, 2, true, 0, 0, false, 8, 1, 0, 27>},
     {"caar_np4_kernel<128, 4, 2, true, 2, 1, false, false, false, 8>", "8 waves x 4 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<128, 4, 2, 2, 1, 0, false, 8, 1, 0>},
     {"caar_np4_kernel<128, 4, 2, true, 1, 1, false, false, false, 8>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 1, 0>},
     {"caar_np4_kernel<128, 4, 2, true, 1, 0, false, false, false, 8>", "8 waves x 4 tiles, nt, update loads one tile ahead", launch_np4<128, 4, 2, true, 0>},
@@ -547,7 +585,7 @@ KernelVariant kNp4Nlev128[] = {
     {"caar_np4_kernel<128, 8, 1, true, 1, 0, false, false, false, 8>", "4 waves x 8 tiles, nt", launch_np4<128, 8, 1, true, 0>},
     {"caar_np4_kernel<128, 2, 4, true, 1, 0, false, false, false, 8>", "16 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<128, 2, 4, true, 0, 0, false, 8, 1, 0>},
     {"caar_np4_kernel<128, 4, 2, true, 2, 0, false, false, false, 8>", "8 waves x 4 tiles, hybrid cache policy, update loads one tile ahead", launch_np4<128, 4, 2, 2, 0>},
-    {"caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8>", "4 waves x 8 tiles, room for 2 waves/SIMD (two workgroups per CU), hybrid cache policy", launch_np4<128, 8, 2, 2, 0>},
+    {"caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8, 15>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / hydrostatic suffix / divdp parked in LDS, hybrid cache policy", launch_np4<128, 8, 2, 2, 0, 0, false, 8, 1, 0, 15>},
 };
 int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 
