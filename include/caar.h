@@ -252,7 +252,7 @@ int caar_selected_variant(int np, int nlev);
 const char *caar_variant_info(int np, int nlev, int variant);
 /* Workgroup -> element mapping: 0 deals consecutive elements round-robin over the XCDs (all XCDs sweep the arrays
  * together); 1 gives each XCD one contiguous eighth of the element range; -1 (default) what the selected variant was
- * measured faster with (the NP=4 NLEV=72 default kernel: 1, +1.3 %; all others: 0).  Same results either way. */
+ * measured faster with (the default kernels of NP=4 NLEV=72 / 128 and NP=8: 1, +0.7..1.3 %; all other variants: 0).  Same results either way. */
 int caar_set_xcd_chunked(int on);
 /* Hybrid cache policy of the default NP=4 kernels: all element data streams with non-temporal
  * loads and stores, which do not allocate in the 256 MB memory-side Infinity Cache — except the

@@ -335,6 +335,11 @@ hipError_t launch_traffic_skeleton_np8(const KernelArgs& k, int nlev, int varian
     case 0: hipLaunchKernelGGL((traffic_skeleton_np4<72, 9, 1, 1, false, 64>), grid, block, 0, s, k); break;
     case 1: hipLaunchKernelGGL((traffic_skeleton_np4<72, 9, 0, 0, false, 64>), grid, block, 0, s, k); break;
     case 2: hipLaunchKernelGGL((traffic_skeleton_np4<72, 9, 1, 1, true, 64>), grid, block, 0, s, k); break;
+    // the element's 8 waves spread over workgroups of 4 / 2 / 1 waves: what more workgroups per CU would be worth
+    case 3: hipLaunchKernelGGL((traffic_skeleton_np4<72, 9, 1, 1, false, 64, 4>), dim3(num_elems * 2), dim3(256), 0, s, k); break;
+    case 4: hipLaunchKernelGGL((traffic_skeleton_np4<72, 9, 1, 1, false, 64, 2>), dim3(num_elems * 4), dim3(128), 0, s, k); break;
+    case 5: hipLaunchKernelGGL((traffic_skeleton_np4<72, 9, 1, 1, false, 64, 1>), dim3(num_elems * 8), dim3(64), 0, s, k); break;
+    case 6: hipLaunchKernelGGL((traffic_skeleton_np4<72, 3, 1, 1, false, 64, 4>), dim3(num_elems * 6), dim3(256), 0, s, k); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

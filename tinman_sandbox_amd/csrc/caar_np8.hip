@@ -379,7 +379,7 @@ static hipError_t launch_np8(const KernelArgs& k, int num_elems, hipStream_t str
 
 // (non-const on purpose, see caar_np4.hip)
 KernelVariant kNp8Nlev72[] = {
-    {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, true, 2>", "8 waves x 9 levels, nt, MFMA contractions, update-phase inputs requested two levels ahead", launch_np8<72, 9, 1, true, false, false, false, true, 2>},
+    {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, true, 2>", "8 waves x 9 levels, nt, MFMA contractions, update-phase inputs requested two levels ahead", launch_np8<72, 9, 1, true, false, false, false, true, 2>, true},
     {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, true, 1>", "8 waves x 9 levels, nt, Dvv contractions on v_mfma_f64_4x4x4 (lane = MFMA result layout, no LDS tile)", launch_np8<72, 9, 1, true, false, false, false, true>},
     {"caar_np8_kernel<72, 9, 1, true, true, true, false, false, false, false, 1>", "8 waves x 9 levels, nt, Dvv slices re-read from LDS", launch_np8<72, 9, 1, true, true, false, false>},
     {"caar_np8_kernel<72, 9, 1, true, true, true, false, true, false, false, 1>", "8 waves x 9 levels, nt, Dvv slices from LDS, operators batched per level", launch_np8<72, 9, 1, true, true, false, true>},

@@ -98,7 +98,7 @@ def main():
     times[("copy", 8)] = []
     times[("copy", 16)] = []
     if a.np_ == 4 or (a.np_ == 8 and a.nlev == 72):
-        for sv in range(min(a.skeletons, 3) if a.np_ == 8 else a.skeletons):
+        for sv in range(min(a.skeletons, 7) if a.np_ == 8 else a.skeletons):
             times[("skeleton", sv)] = []
     for _ in range(a.rounds):
         for key in list(times):
