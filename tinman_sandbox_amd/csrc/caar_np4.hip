@@ -18,9 +18,12 @@
 //   * the three vertical integrals (pressure, geopotential, omega) are blocked
 //     scans: in-wave over the 4 levels of a tile, tile totals through LDS, two
 //     workgroup barriers.  Everything else stays in registers from load to store.
-//   * every array is streamed exactly once per launch: non-temporal loads/stores, and the
-//     update-phase inputs are requested before the last barrier so that they are in
-//     flight while the integrals finish.  Measured HBM traffic = algorithmic bytes x1.0002.
+//   * every array is streamed exactly once per launch (non-temporal loads/stores; measured HBM-side traffic =
+//     algorithmic bytes x1.0002), except that the default kernels keep the three read-modify-write accumulators of
+//     part of the elements in the 256 MB Infinity Cache between calls (POL = 2).
+//   * the default launch shapes put TWO workgroups (two elements in different phases) on a CU: NLEV=72 3 waves x 6
+//     tiles (253 VGPRs), NLEV=128 4 waves x 8 tiles with four scan results parked in LDS (PARK).  With the cache
+//     window that is worth 76 -> 83 % of the HBM peak at NLEV=72.
 #include <hip/hip_runtime.h>
 
 #include "caar_kernel_args.h"
