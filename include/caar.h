@@ -171,8 +171,7 @@ int caar_sphere_operator_range(const CaarDims *dims, const CaarArrays *dev, cons
  *   11 DIVERGENCE_SPHERE_UPDATE            v  -> s = beta*s + alpha*div   Dinv, metdet, rmetdet  K:363-403
  *   12 VLAPLACE_SPHERE_WK_CARTESIAN_DAMPED v  -> v          as 9, without the rigid-rotation term  K:777-844
  * Codes 1, 2, 8, 11 multiply by rmetdet (the pointers_only operators' form, sphere_operators.cpp:85,125)
- * where K: forms 1/metdet on the fly.  The EulerStep functor (EulerStepFunctor.hpp:32-68) is NOT provided:
- * the reference's own call of divergence_sphere_update does not match its declaration. */
+ * where K: forms 1/metdet on the fly.  The EulerStep functor (EulerStepFunctor.hpp:32-68): caar_euler_step below. */
 enum {
   CAAR_OP_GRADIENT_SPHERE = 0,
   CAAR_OP_DIVERGENCE_SPHERE = 1,
@@ -205,6 +204,19 @@ typedef struct CaarOperatorScalars {
 int caar_sphere_operator_ex(const CaarDims *dims, const CaarOperatorGeometry *geo, const double *dvv_dev, int which,
                             int e0, int e1, int nlevels, const double *in_dev, double *out_dev,
                             const CaarOperatorScalars *scalars, void *stream);
+
+/* The tracer step sketched in EulerStepFunctor.hpp:32-68 (Kokkos variant; not compilable as it stands — its call
+ * of divergence_sphere_update, E:65-66, passes 8 arguments to the 9-parameter K:363-370 — so this follows what the
+ * functor STATES, parity unpinned): for every tracer q < qsize and every level
+ *     vstar_qdp = vstar * Qdp(qn0, q)   (E:59-60)      qtens(q) = Qdp(qn0, q)   (E:61)
+ *     qtens(q)  = 1.0 * qtens(q) + (-dt) * divergence_sphere(vstar_qdp)          (E:65-66, K:398-399)
+ * fused into one pass: vstar is read once per level for all tracers, no vstar_qdp buffer.
+ * vstar_dev [e1-e0][nlev][np][np][2] (16-byte aligned), Qdp_dev = CaarArrays.state_Qdp of element 0
+ * ([ie][qsize_d][2][nlev][np][np], dims->qsize_d), qtens_dev [e1-e0][qsize][nlev][np][np]; geo: Dinv, metdet,
+ * rmetdet of element 0.  Asynchronous on `stream`. */
+int caar_euler_step(const CaarDims *dims, const CaarOperatorGeometry *geo, const double *dvv_dev, int e0, int e1,
+                    int qsize, int qn0, double dt, double rrearth, const double *vstar_dev, const double *Qdp_dev,
+                    double *qtens_dev, void *stream);
 
 /* The two vertical integrals of the path as functions of their own (reference:
  * compute_and_apply_rhs.hpp:11-17, P:280-352), batched over `nelem` columns-of-elements:

@@ -148,6 +148,10 @@ void oracle_vlaplace_sphere_wk_contra(int np, const double *v, const double *Dvv
                                       const double *mp, const double *spheremp, const double *metinv, const double *metdet,
                                       double nu_ratio, double rrearth, double *lap);           /* K:938-993 */
 
+/* EulerStepFunctor.hpp:32-68, one element: qtens = Qdp(qn0) - dt * div(vstar * Qdp(qn0)) per tracer and level */
+void oracle_euler_step(int np, int nlev, int qsize, int qn0, double dt, const double *vstar, const double *qdp,
+                       const double *Dvv, const double *Dinv, const double *metdet, double rrearth, double *qtens);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,7 +124,8 @@ class Oracle:
                 "oracle_laplace_tensor": [i, d, d, d, d, d, f, d], "oracle_curl_sphere_wk_testcov": [i, d, d, d, d, f, d],
                 "oracle_grad_sphere_wk_testcov": [i, d, d, d, d, d, d, f, d],
                 "oracle_vlaplace_sphere_wk_cartesian": [i, d, d, d, d, d, d, f, i, d],
-                "oracle_vlaplace_sphere_wk_contra": [i, d, d, d, d, d, d, d, d, f, f, d]}.items():
+                "oracle_vlaplace_sphere_wk_contra": [i, d, d, d, d, d, d, d, d, f, f, d],
+                "oracle_euler_step": [i, i, i, i, f, d, d, d, d, d, f, d]}.items():
             getattr(L, name).argtypes = args
             getattr(L, name).restype = None
 
@@ -263,6 +264,17 @@ def sphere_op(O, name, x, Dvv, geo, rrearth, out=None, alpha=1.0, beta=0.0, nu_r
     else:
         raise KeyError(name)
     return res
+
+
+def euler_step(O, vstar, qdp, qsize, qn0, dt, Dvv, Dinv, metdet, rrearth):
+    """EulerStepFunctor.hpp:32-68 of ONE element through the C oracle (PARITY UNPINNED): vstar [nlev][np][np][2],
+    qdp [qsize_d][2][nlev][np][np] -> qtens [qsize][nlev][np][np]."""
+    nlev, np_ = vstar.shape[0], vstar.shape[1]
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (vstar, qdp, Dvv, Dinv, metdet)]
+    qtens = np.zeros((qsize, nlev, np_, np_))
+    O.lib.oracle_euler_step(np_, nlev, qsize, qn0, dt, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(a[4]), rrearth,
+                            _ptr(qtens))
+    return qtens
 
 
 def ref_lib_path(np_, nlev):

@@ -245,3 +245,25 @@ void oracle_vlaplace_sphere_wk_contra(int np, const double *v, const double *Dvv
         KV(lap, h, igp, jgp) = r;
       }
 }
+
+/* EulerStepFunctor.hpp:32-68 (E:), one element: for every tracer and level  v_buf = vstar * qdp (E:59-60),
+ * q_buf = qdp (E:61), divergence_sphere_update(-dt, 1.0, ..., v_buf, q_buf) (E:65-66).  The reference cannot compile
+ * the functor (8 arguments for the 9 parameters of K:363-370): PARITY UNPINNED, this is what it states.
+ * vstar [nlev][np][np][2]; qdp [qsize_d][2][nlev][np][np] (the element's slice of state_Qdp); qtens [qsize][nlev][np][np]. */
+void oracle_euler_step(int np, int nlev, int qsize, int qn0, double dt, const double *vstar, const double *qdp,
+                       const double *Dvv, const double *Dinv, const double *metdet, double rrearth, double *qtens) {
+  const int pp = np * np;
+  double v_buf[2 * MAXNP * MAXNP];
+  for (int iq = 0; iq < qsize; ++iq)
+    for (int ilev = 0; ilev < nlev; ++ilev) {
+      const double *q = qdp + ((size_t)(iq * 2 + qn0) * nlev + ilev) * pp;
+      const double *vs = vstar + (size_t)ilev * pp * 2;
+      double *q_buf = qtens + ((size_t)iq * nlev + ilev) * pp;
+      for (int idx = 0; idx < pp; ++idx) {
+        v_buf[2 * idx + 0] = vs[2 * idx + 0] * q[idx]; /* E:59 */
+        v_buf[2 * idx + 1] = vs[2 * idx + 1] * q[idx]; /* E:60 */
+        q_buf[idx] = q[idx];                           /* E:61 */
+      }
+      oracle_divergence_sphere_update(np, -dt, 1.0, v_buf, Dvv, Dinv, metdet, rrearth, q_buf); /* E:65-66 */
+    }
+}

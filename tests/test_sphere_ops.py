@@ -174,6 +174,41 @@ def test_polynomial_exactness_of_the_weak_laplacian(oracle):
 
 
 # --------------------------------------------------------------------------------------- GPU: HIP vs the oracle
+@pytest.mark.parametrize("np_", NPS)
+def test_euler_step_oracle(oracle, np_):
+    """oracle_euler_step (EulerStepFunctor.hpp:32-68, parity unpinned) is Qdp - dt * div(vstar * Qdp) with the
+    divergence whose index mapping the first test pins; it reads only time level qn0 and the first qsize tracers; it is
+    linear in Qdp; and a constant flux on the identity geometry leaves the tracer unchanged."""
+    Dvv = cases.dvv_for(np_, "double" if np_ == 4 else "gll")
+    g = geometry(np_, 2, 21)
+    nlev, qsize_d, qsize, qn0, dt = 5, 3, 2, 1, 0.8
+    vstar = cases.uniform((nlev, np_, np_, 2), 801, -3, 5)
+    qdp = cases.uniform((qsize_d, 2, nlev, np_, np_), 802, 0.5, 2.0)
+    e = elem(g, 1)
+    got = po.euler_step(oracle, vstar, qdp, qsize, qn0, dt, Dvv, e["Dinv"], e["metdet"], RR)
+    for q in range(qsize):
+        for k in range(nlev):
+            d = po.sphere_op(oracle, "divergence_sphere", vstar[k] * qdp[q, qn0, k][..., None], Dvv, e, RR)
+            assert np.array_equal(got[q, k], qdp[q, qn0, k] * 1.0 + (-dt) * d)
+    # the other time level and the tracers beyond qsize are not read
+    qdp2 = qdp.copy()
+    qdp2[:, 1 - qn0] = 7.0
+    qdp2[qsize:] = -3.0
+    assert np.array_equal(po.euler_step(oracle, vstar, qdp2, qsize, qn0, dt, Dvv, e["Dinv"], e["metdet"], RR), got)
+    # linear in Qdp
+    both = po.euler_step(oracle, vstar, 2.0 * qdp, qsize, qn0, dt, Dvv, e["Dinv"], e["metdet"], RR)
+    assert close(both, 2.0 * got, 1e-15)
+    # constant flux on the identity geometry: the divergence of a constant vanishes (Dvv^T rows sum to zero: see the
+    # note on the reference's transposed Dvv in test_polynomial_exactness_of_the_weak_laplacian)
+    ident = np.zeros((np_, np_, 2, 2))
+    ident[..., 0, 0] = ident[..., 1, 1] = 1.0
+    ones = np.ones((np_, np_))
+    qc = np.full((1, 2, nlev, np_, np_), 1.5)
+    vc = np.full((nlev, np_, np_, 2), 2.0)
+    stay = po.euler_step(oracle, vc, qc, 1, 0, dt, np.ascontiguousarray(Dvv.T), ident, ones, RR)
+    assert float(np.max(np.abs(stay - 1.5))) <= 1e-12
+
+
 def _oracle_all(oracle, name, x, Dvv, g, e0, **kw):
     ne, nl = x.shape[:2]
     vout = po.SPHERE_OPS[name][1]
@@ -244,6 +279,52 @@ def test_hip_update_operators_match_oracle(oracle, np_):
     got = tsa.sphere_operator_ex("divergence_sphere_update", torch.from_numpy(v).cuda(), dev, dvv, RR,
                                  out=torch.from_numpy(acc_s.copy()).cuda(), alpha=0.75, beta=-1.5)
     assert float(np.max(np.abs(got.cpu().numpy() - want))) <= 1e-12 * float(np.max(np.abs(want)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("np_,nlev,qsize_d,qsize", [(4, 72, 4, 4), (4, 11, 3, 2), (8, 9, 2, 2), (4, 6, 1, 1)])
+def test_hip_euler_step_matches_oracle(oracle, np_, nlev, qsize_d, qsize):
+    """caar_euler_step (EulerStepFunctor.hpp:32-68; parity unpinned) against oracle_euler_step: elements 1..4 of a
+    6-element set, both Qdp time levels, fewer tracers than allocated, a partly filled last tile (NP=4, nlev 11 / 6)."""
+    import torch
+    import tinman_sandbox_amd as tsa
+    Dvv = cases.dvv_for(np_, "double" if np_ == 4 else "gll")
+    g = geometry(np_, 6, 22)
+    dev = {k: torch.from_numpy(g[k]).cuda() for k in ("Dinv", "metdet", "rmetdet")}
+    ne, e0, dt = 4, 1, 0.6
+    vstar = cases.uniform((ne, nlev, np_, np_, 2), 811, -3, 5)
+    qdp = cases.uniform((6, qsize_d, 2, nlev, np_, np_), 812, 0.5, 2.0)
+    for qn0 in (0, 1):
+        want = np.stack([po.euler_step(oracle, vstar[e], qdp[e0 + e], qsize, qn0, dt, Dvv, g["Dinv"][e0 + e],
+                                       g["metdet"][e0 + e], RR) for e in range(ne)])
+        got = tsa.euler_step(torch.from_numpy(vstar).cuda(), torch.from_numpy(qdp).cuda(), dev,
+                             torch.from_numpy(Dvv).cuda(), qsize, qn0, dt, RR, e0=e0)
+        torch.cuda.synchronize()
+        err = float(np.max(np.abs(got.cpu().numpy() - want)))
+        assert err <= 1e-12 * float(np.max(np.abs(want))), (np_, nlev, qn0, err)
+
+
+@pytest.mark.gpu
+def test_euler_step_validates_its_arguments():
+    import ctypes as C
+    import torch
+    import tinman_sandbox_amd as tsa
+    from tinman_sandbox_amd import caar as m
+    lib = tsa.library().lib
+    z = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    vp = C.c_void_p(z.data_ptr())
+    geo = m._CaarOperatorGeometry()
+    geo.Dinv = geo.metdet = geo.rmetdet = z.data_ptr()
+    dims = m._CaarDims(4, 3, 2, 1, 2)
+    call = lambda d, g_, e0, e1, qs, qn0: lib.caar_euler_step(C.byref(d), C.byref(g_), vp, e0, e1, qs, qn0, 1.0, 1.0, vp,
+                                                              vp, vp, None)
+    assert call(dims, geo, 0, 2, 2, 0) == 0
+    assert call(dims, geo, 0, 3, 2, 0) == -1   # beyond num_elems
+    assert call(dims, geo, 0, 2, 3, 0) == -1   # more tracers than qsize_d
+    assert call(dims, geo, 0, 2, 2, 2) == -1   # Qdp has two time levels
+    assert call(dims, m._CaarOperatorGeometry(), 0, 2, 2, 0) == -1  # no geometry
+    assert call(m._CaarDims(5, 3, 2, 1, 2), geo, 0, 2, 2, 0) == -2   # unsupported np
+    torch.cuda.synchronize()
 
 
 @pytest.mark.gpu

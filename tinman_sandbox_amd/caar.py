@@ -79,7 +79,7 @@ class CaarLibrary:
     """ctypes view of libcaar_hip.so; every symbol of include/caar.h is bound here."""
 
     SYMBOLS = ("caar_supported", "caar_abi_version", "caar_device_count", "caar_strerror", "caar_array_len",
-               "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator", "caar_sphere_operator_range", "caar_sphere_operator_ex", "caar_preq_hydrostatic", "caar_preq_omega_ps", "caar_sphere_operator_host", "caar_preq_hydrostatic_host", "caar_preq_omega_ps_host", "caar_reciprocal",
+               "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator", "caar_sphere_operator_range", "caar_sphere_operator_ex", "caar_euler_step", "caar_preq_hydrostatic", "caar_preq_omega_ps", "caar_sphere_operator_host", "caar_preq_hydrostatic_host", "caar_preq_omega_ps_host", "caar_reciprocal",
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
                "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_selected_variant", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_stream_copy_tuned", "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_arrays_alloc", "caar_arrays_free", "caar_arrays_placement", "caar_create", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_download_f90",
                "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
@@ -109,6 +109,8 @@ class CaarLibrary:
                                            C.c_int, vp, vp, C.c_double, vp]
         L.caar_sphere_operator_range.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays), vp, C.c_int, C.c_int,
                                                  C.c_int, C.c_int, vp, vp, C.c_double, vp]
+        L.caar_euler_step.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarOperatorGeometry), vp, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_double, C.c_double, vp, vp, vp, vp]
         L.caar_sphere_operator_ex.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarOperatorGeometry), vp, C.c_int, C.c_int,
                                               C.c_int, C.c_int, vp, vp, C.POINTER(_CaarOperatorScalars), vp]
         L.caar_preq_hydrostatic.argtypes = [C.POINTER(_CaarDims), C.c_int, vp, vp, vp, vp, C.c_double, vp, vp]
@@ -612,6 +614,38 @@ def sphere_operator_ex(name, field, geometry, Dvv, rrearth, out=None, alpha=1.0,
     L.check(L.lib.caar_sphere_operator_ex(C.byref(dims), C.byref(g), C.c_void_p(dv.data_ptr()), code, e0, e0 + ne, nl,
                                           C.c_void_p(f.data_ptr()), C.c_void_p(out.data_ptr()), C.byref(sc),
                                           C.c_void_p(stream.cuda_stream)), "caar_sphere_operator_ex")
+    return out
+
+
+def euler_step(vstar, Qdp, geometry, Dvv, qsize, qn0, dt, rrearth, e0=0, out=None):
+    """The tracer step of the reference's EulerStepFunctor.hpp:32-68 (caar_euler_step): qtens(q) = Qdp(qn0, q) -
+    dt * divergence_sphere(vstar * Qdp(qn0, q)) for q < qsize.  Device tensors: `vstar` [ne][nlev][np][np][2] for the
+    elements e0 .. e0+ne-1, `Qdp` the whole [num_elems][qsize_d][2][nlev][np][np] array, `geometry` a dict with Dinv,
+    metdet, rmetdet [num_elems][np][np](...), `Dvv` [np][np].  Returns qtens [ne][qsize][nlev][np][np]."""
+    L = library()
+    v, q = vstar.contiguous(), Qdp.contiguous()
+    if not v.is_cuda or v.dtype != torch.float64 or not q.is_cuda or q.dtype != torch.float64:
+        raise CaarError("euler_step needs float64 device tensors (no CPU fallback)")
+    ne, nl, np_ = v.shape[0], v.shape[1], v.shape[2]
+    assert tuple(v.shape) == (ne, nl, np_, np_, 2)
+    num_elems, qsize_d = q.shape[0], q.shape[1]
+    assert tuple(q.shape) == (num_elems, qsize_d, 2, nl, np_, np_) and e0 + ne <= num_elems
+    if out is None:
+        out = torch.empty((ne, qsize, nl, np_, np_), dtype=torch.float64, device=v.device)
+    assert tuple(out.shape) == (ne, qsize, nl, np_, np_) and out.is_contiguous() and out.dtype == torch.float64
+    g = _CaarOperatorGeometry()
+    keep = []
+    for n in ("Dinv", "metdet", "rmetdet"):
+        t = geometry[n].contiguous()
+        assert t.shape[0] == num_elems
+        keep.append(t)
+        setattr(g, n, t.data_ptr())
+    dims = _CaarDims(np_, nl, qsize_d, 1, num_elems)
+    dv = Dvv.contiguous()
+    stream = torch.cuda.current_stream(v.device)
+    L.check(L.lib.caar_euler_step(C.byref(dims), C.byref(g), C.c_void_p(dv.data_ptr()), e0, e0 + ne, qsize, qn0, dt,
+                                  rrearth, C.c_void_p(v.data_ptr()), C.c_void_p(q.data_ptr()),
+                                  C.c_void_p(out.data_ptr()), C.c_void_p(stream.cuda_stream)), "caar_euler_step")
     return out
 
 

@@ -35,16 +35,9 @@ hipError_t launch_stream_copy_tuned(double* dst, const double* src, size_t n_dou
 int stream_copy_tuned_variants();
 const char* stream_copy_tuned_info(int v);
 hipError_t launch_reciprocal(const double* in, double* out, size_t n, hipStream_t s);
-struct OpArgs {  // caar_operators_ex.hip
-  const double *D, *Dinv, *metdet, *rmetdet, *spheremp, *mp, *metinv, *tensorVisc, *vec_sph2cart;
-  const double* dvv;
-  const double* in;
-  double* out;
-  int e0, ne, nlevels;
-  double rrearth, alpha, beta, nu_ratio;
-};
 hipError_t launch_sphere_operator_ex(int np, int which, const OpArgs& a, hipStream_t s);
 unsigned sphere_operator_ex_needs(int which);
+hipError_t launch_euler_step(int np, const EulerArgs& a, hipStream_t s);
 hipError_t launch_preq_hydrostatic(int np, int nlev, int nelem, const double* phis, const double* Tv, const double* p,
                                    const double* dp, double Rgas, double* phi, hipStream_t s);
 hipError_t launch_preq_omega_ps(int np, int nlev, int nelem, const double* p, const double* vgrad_p, const double* divdp,
@@ -444,6 +437,24 @@ int caar_sphere_operator_ex(const CaarDims* dims, const CaarOperatorGeometry* ge
   a.beta = sc->beta;
   a.nu_ratio = sc->nu_ratio;
   return (int)caar::launch_sphere_operator_ex(dims->np, which, a, (hipStream_t)stream);
+}
+
+int caar_euler_step(const CaarDims* dims, const CaarOperatorGeometry* geo, const double* dvv_dev, int e0, int e1,
+                    int qsize, int qn0, double dt, double rrearth, const double* vstar_dev, const double* Qdp_dev,
+                    double* qtens_dev, void* stream) {
+  if (!dims || !geo || !dvv_dev || !vstar_dev || !Qdp_dev || !qtens_dev) return CAAR_EINVAL;
+  if (e0 < 0 || e1 > dims->num_elems || e0 > e1) return CAAR_EINVAL;
+  if (qsize < 0 || qsize > dims->qsize_d || qn0 < 0 || qn0 > 1 || dims->nlev < 1) return CAAR_EINVAL;
+  if (dims->np != 4 && dims->np != 8) return CAAR_EUNSUPPORTED;
+  if (!geo->Dinv || !geo->metdet || !geo->rmetdet) return CAAR_EINVAL;
+  if ((((size_t)geo->Dinv) | ((size_t)vstar_dev)) & 15) return CAAR_EINVAL;  // move as 16-byte pairs
+  if ((((size_t)geo->metdet) | ((size_t)geo->rmetdet) | ((size_t)Qdp_dev) | ((size_t)qtens_dev)) & 7) return CAAR_EINVAL;
+  caar::EulerArgs a;
+  a.Dinv = geo->Dinv; a.metdet = geo->metdet; a.rmetdet = geo->rmetdet; a.dvv = dvv_dev;
+  a.vstar = vstar_dev; a.qdp = Qdp_dev; a.qtens = qtens_dev;
+  a.e0 = e0; a.ne = e1 - e0; a.nlev = dims->nlev; a.qsize = qsize; a.qsize_d = dims->qsize_d; a.qn0 = qn0;
+  a.dt = dt; a.rrearth = rrearth;
+  return (int)caar::launch_euler_step(dims->np, a, (hipStream_t)stream);
 }
 
 int caar_preq_hydrostatic(const CaarDims* dims, int nelem, const double* phis_dev, const double* T_v_dev,

@@ -106,5 +106,22 @@ struct KernelVariant {
   bool prefers_xcd_chunked = false;  // measured faster with each XCD on a contiguous eighth of the element range
 };
 
+// arguments of the stand-alone operator kernels (caar_operators_ex.hip)
+struct OpArgs {
+  const double *D, *Dinv, *metdet, *rmetdet, *spheremp, *mp, *metinv, *tensorVisc, *vec_sph2cart;
+  const double* dvv;
+  const double* in;
+  double* out;
+  int e0, ne, nlevels;
+  double rrearth, alpha, beta, nu_ratio;
+};
+struct EulerArgs {
+  const double *Dinv, *metdet, *rmetdet, *dvv;
+  const double *vstar, *qdp;
+  double* qtens;
+  int e0, ne, nlev, qsize, qsize_d, qn0;
+  double dt, rrearth;
+};
+
 }  // namespace caar
 #endif

@@ -26,15 +26,6 @@
 
 namespace caar {
 
-struct OpArgs {
-  const double *D, *Dinv, *metdet, *rmetdet, *spheremp, *mp, *metinv, *tensorVisc, *vec_sph2cart;
-  const double* dvv;
-  const double* in;
-  double* out;
-  int e0, ne, nlevels;
-  double rrearth, alpha, beta, nu_ratio;
-};
-
 // contraction providers ---------------------------------------------------------------------------
 struct X4 {  // NP=4: lane = sub*16 + a*4 + b
   RowCoef c, ct;
@@ -277,6 +268,67 @@ hipError_t launch_sphere_operator_ex(int np, int which, const OpArgs& a, hipStre
   if (np == 4) return launch_ex_np<4>(which, a, s);
   if (np == 8) return launch_ex_np<8>(which, a, s);
   return hipErrorInvalidValue;
+}
+
+// ---- the tracer step sketched in EulerStepFunctor.hpp:32-68 --------------------------------------------------
+// What the functor states, per tracer q and level: vstar_qdp = vstar * Qdp(qn0, q) (E:59-60); qtens = Qdp(qn0, q)
+// (E:61); divergence_sphere_update(alpha = -dt, beta = 1.0, v = vstar_qdp, div_v = qtens) (E:65-66), i.e.
+// qtens = Qdp - dt * div(vstar * Qdp).  The reference cannot compile it (the call passes 8 arguments to the
+// 9-parameter K:363-370); this kernel is that statement, fused: vstar of a level is read ONCE for all tracers,
+// Qdp once, qtens written once, no vstar_qdp buffer.  (2 + 2 qsize) field blocks of traffic per element.
+template <int NP>
+__global__ __launch_bounds__(256) void euler_step_kernel(const EulerArgs a) {
+  constexpr int PP = NP * NP;
+  __shared__ double s_dvv[PP];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  for (int i = tid; i < PP; i += blockDim.x) s_dvv[i] = a.dvv[i];
+  __syncthreads();
+  typename std::conditional<NP == 4, X4, X8>::type x;
+  int pt, sub;
+  if constexpr (NP == 4) {
+    x.c = x.ct = make_row_coef(s_dvv, lane);
+    pt = lane & 15;
+    sub = lane >> 4;
+  } else {
+    x.c = x.ct = np8::make_mfma_ctx(s_dvv, lane);
+    pt = np8::mfma_point(lane);
+    sub = 0;
+  }
+  constexpr int LPT = NP == 4 ? 4 : 1;
+  const int nsteps = (a.nlev + LPT - 1) / LPT;
+  const size_t block = (size_t)a.nlev * PP;  // one field block
+  for (int e = blockIdx.x; e < a.ne; e += gridDim.x) {
+    const size_t g = (size_t)(a.e0 + e) * PP + pt;
+    const T22 Dinv = load_t22(a.Dinv, g);
+    const double metdet = a.metdet[g], rmetdet = a.rmetdet[g];
+    const double* qdp_e = a.qdp + ((size_t)(a.e0 + e) * a.qsize_d * 2 + a.qn0) * block;  // + q * 2 * block
+    double* qtens_e = a.qtens + (size_t)e * a.qsize * block;                                  // + q * block
+    for (int st = w; st < nsteps; st += nw) {
+      const int lev = st * LPT + sub;
+      const bool live = lev < a.nlev;
+      const size_t o = (size_t)lev * PP + pt;
+      dbl2 vs = {0, 0};
+      if (live) vs = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(a.vstar) + (size_t)e * block + o);
+      double q_next = live && a.qsize > 0 ? __builtin_nontemporal_load(qdp_e + o) : 0.0;
+      for (int q = 0; q < a.qsize; ++q) {  // wave-uniform trip count
+        const double qdp = q_next;
+        if (q + 1 < a.qsize && live) q_next = __builtin_nontemporal_load(qdp_e + (size_t)(q + 1) * 2 * block + o);
+        const double div = op_divergence(x, Dinv, metdet, rmetdet, a.rrearth, V2{vs.x * qdp, vs.y * qdp});
+        double t = qdp * 1.0;  // K:398 with beta = 1.0
+        t += -a.dt * div;      // K:399 with alpha = -dt
+        if (live) __builtin_nontemporal_store(t, qtens_e + (size_t)q * block + o);
+      }
+    }
+  }
+}
+
+hipError_t launch_euler_step(int np, const EulerArgs& a, hipStream_t s) {
+  if (a.ne <= 0 || a.qsize <= 0 || a.nlev <= 0) return hipSuccess;
+  const dim3 grid(a.ne < 65536 ? a.ne : 65536), block(256);
+  if (np == 4) hipLaunchKernelGGL((euler_step_kernel<4>), grid, block, 0, s, a);
+  else if (np == 8) hipLaunchKernelGGL((euler_step_kernel<8>), grid, block, 0, s, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
 }
 
 // which geometry arrays operator `which` reads (bit i = member i of CaarOperatorGeometry), for validation

@@ -51,5 +51,13 @@ for np_, nlev, E in ((4, 72, 10000), (4, 128, 12500), (8, 72, 20000)):
         ms, out = timed(lambda: tsa.sphere_operator_ex(name, f, geo, dvv, 1.5e-7, out=acc if upd else None))
         byts = (f.numel() + out.numel() * (2 if upd else 1)) * 8
         print("  %-40s %7.3f ms  %6.0f GB/s" % (name, ms, byts / ms / 1e6), flush=True)
+    # the tracer step (caar_euler_step; EulerStepFunctor.hpp:32-68): 2 + 2 qsize field blocks per element
+    for qsize in (1, 4):
+        qdp = rnd(E, qsize, 2, nlev, np_, np_)
+        qt = torch.empty((E, qsize, nlev, np_, np_), dtype=torch.float64, device="cuda")
+        ms, out = timed(lambda: tsa.euler_step(v, qdp, geo, dvv, qsize, 0, 0.5, 1.5e-7, out=qt))
+        byts = (v.numel() + 2 * out.numel()) * 8
+        print("  %-40s %7.3f ms  %6.0f GB/s" % ("euler_step qsize=%d" % qsize, ms, byts / ms / 1e6), flush=True)
+        del qdp, qt
     del data, geo
     torch.cuda.empty_cache()
