@@ -98,6 +98,17 @@ __device__ __forceinline__ void stream_store(T* p, T v) {
   else *p = v;
 }
 
+// Pointer for RE-READING values a kernel parked in LDS to free registers.  The compiler must not replace such a read by the
+// register copy of what was stored (that is the point of parking), so the address is laundered through an empty asm; the
+// access stays a plain ds_read_b64 in the LDS address space.  (A `volatile` generic pointer does the job too, but compiles to
+// flat_load sc0 sc1 + s_waitcnt vmcnt(0): every parked read then also drains all outstanding global loads.)
+using lds_cptr = const __attribute__((address_space(3))) double*;
+__device__ __forceinline__ lds_cptr lds_reread_ptr(const double* generic_ptr_into_shared) {
+  unsigned a = (unsigned)(size_t)(lds_cptr)generic_ptr_into_shared;
+  asm volatile("" : "+v"(a));
+  return (lds_cptr)(size_t)a;
+}
+
 // One compiled kernel configuration for a given (np, nlev).
 struct KernelVariant {
   const char* kernel;  // demangled kernel name as rocprofv3 prints it

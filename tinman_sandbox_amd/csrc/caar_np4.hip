@@ -105,14 +105,19 @@ struct Np4Lds {
   double col[3][COL];
   double hybi[VADV ? NT_MAX * 4 + 1 : 1];
   // PARK (bit mask): p (1), the divdp prefix (2), the in-tile hydrostatic suffix (4), divdp (8), T_v (16) of every point
-  // wait here between the phases ([slot][tile * 64 + lane]; each lane re-reads only what it wrote)
+  // wait here between the phases ([slot][tile * 64 + lane]; each lane re-reads only what it wrote); 32 (Eulerian form):
+  // u, v, T are re-read from `col` in the last phase instead of staying in registers
   static constexpr int NPARK = (PARK & 1) + ((PARK >> 1) & 1) + ((PARK >> 2) & 1) + ((PARK >> 3) & 1) + ((PARK >> 4) & 1);
   double park[NPARK ? NPARK : 1][NPARK ? NT_MAX * 64 : 1];
 };
 
 // PARK: the five per-point values that live from the scans to the last phase (p, divdp prefix, hydrostatic in-tile suffix,
 // divdp, T_v) wait in LDS instead of registers (10 VGPRs per tile): lets a fat shape (few waves x many tiles) stay within
-// 256 registers, i.e. two workgroups per CU, where the level count makes the tiles-per-wave large (NLEV=128: 4 waves x 8).
+// 256 registers, i.e. two workgroups per CU, where the level count makes the tiles-per-wave large (NLEV=128: 4 waves x 8)
+// or the form holds more per level (Eulerian, NLEV=72: 3 waves x 6 with p, divdp prefix, divdp parked and u, v, T re-read from
+// the column copy).  The re-reads go through lds_reread_ptr (plain ds_read_b64): near free, 82.9 % against 83.6 % unparked at
+// NLEV=72.  (Round 2 first had them as `volatile` generic loads = flat_load sc0 sc1 + s_waitcnt vmcnt(0), which drained the
+// global loads in flight at every parked read: 75.4 %.)
 template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW, int PARK = 0>
 __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW, PARK>& lds) {
   constexpr int PP = 16;               // GLL points per level
@@ -127,7 +132,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   static_assert(DYN || NT_MAX % TPW == 0, "tile decomposition");
   static_assert(!RAGGED || !PERSIST, "ragged level counts: non-persistent form only");
   static_assert(!VADV || (!PERSIST && !ETA_COND), "Eulerian branch: plain form only");
-  static_assert(PARK == 0 || (!RAGGED && !PERSIST && !VADV), "PARK: plain vertically-Lagrangian form, level count a multiple of 4");
+  static_assert(PARK == 0 || (!RAGGED && !PERSIST), "PARK: non-persistent form, level count a multiple of 4");
 
   static_assert(G_SIZE == 208, "Np4Lds::geo_buf");
   double* const s_dvv = lds.dvv;
@@ -398,7 +403,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         divdp_r = divdp[r];
         Tv_r = Tv[r];
       } else {
-        const volatile double* pk = &lds.park[0][0] + t * 64 + lane;  // volatile: must not be forwarded through registers
+        const lds_cptr pk = lds_reread_ptr(&lds.park[0][0] + t * 64 + lane);  // must not be forwarded through registers
         constexpr int Q = NT_MAX * 64;
         constexpr int S1 = PARK & 1, S2 = S1 + ((PARK >> 1) & 1), S3 = S2 + ((PARK >> 2) & 1), S4 = S3 + ((PARK >> 3) & 1);
         if constexpr (PARK & 1) p_r = pk[0]; else p_r = p[r];
@@ -409,6 +414,19 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       }
       double rp_r;
       if constexpr (PARK & 1) rp_r = recip(p_r); else rp_r = rp[r];
+      // PARK bit 32 (Eulerian form only): u, v, T of this tile are re-read from the column copy phase 1 left in LDS
+      double u_r, v_r, T_r;
+      if constexpr (VADV && (PARK & 32)) {
+        const lds_cptr cc = lds_reread_ptr(&s_col[0][0] + PP + t * 64 + lane);
+        constexpr int CS = sizeof(s_col[0]) / sizeof(double);
+        T_r = cc[0];
+        u_r = cc[CS];
+        v_r = cc[2 * CS];
+      } else {
+        u_r = u[r];
+        v_r = v[r];
+        T_r = T[r];
+      }
 
       const double ht = (k.Rgas * Tv_r) * (dp[r] * rp_r);         // same expression as in phase 2
       const double phi = (phis + (below + exht_r)) + 0.5 * ht;    // P:303,309
@@ -416,21 +434,21 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
 
       double gp0, gp1;
       gradient_sphere(c, Dinv, rrearth, p_r, gp0, gp1);            // P:103
-      const double vgrad_p = u[r] * gp0 + v[r] * gp1;               // P:111
+      const double vgrad_p = u_r * gp0 + v_r * gp1;               // P:111
       const double ckk = 0.5 * rp_r, ckl = rp_r;                  // P:333-334 (ckl = 2*ckk)
       const double om = vgrad_p * rp_r - ckl * suml_r - ckk * divdp_r;  // P:325,336,348
-      const double vort = vorticity_sphere(c, Dm, rmetdet, rrearth, u[r], v[r]);  // P:122
+      const double vort = vorticity_sphere(c, Dm, rmetdet, rrearth, u_r, v_r);  // P:122
 
-      const double Ephi = 0.5 * (u[r] * u[r] + v[r] * v[r]) + phi + cur.pec;  // P:196
+      const double Ephi = 0.5 * (u_r * u_r + v_r * v_r) + phi + cur.pec;  // P:196
       double gT0, gT1, gE0, gE1;
-      gradient_sphere(c, Dinv, rrearth, T[r], gT0, gT1);            // P:200
-      const double vgrad_T = u[r] * gT0 + v[r] * gT1;               // P:209
+      gradient_sphere(c, Dinv, rrearth, T_r, gT0, gT1);            // P:200
+      const double vgrad_T = u_r * gT0 + v_r * gT1;               // P:209
       gradient_sphere(c, Dinv, rrearth, Ephi, gE0, gE1);            // P:213
       const double gpterm = Tv_r * rp_r;                          // P:219
       const double glnps1 = k.Rgas * gpterm * gp0;                  // P:221
       const double glnps2 = k.Rgas * gpterm * gp1;                  // P:222
-      double vtens1 = v[r] * (fcor + vort) - gE0 - glnps1;          // P:227 (v_vadv == 0)
-      double vtens2 = -u[r] * (fcor + vort) - gE1 - glnps2;         // P:228
+      double vtens1 = v_r * (fcor + vort) - gE0 - glnps1;          // P:227 (v_vadv == 0)
+      double vtens2 = -u_r * (fcor + vort) - gE1 - glnps2;         // P:228
       double ttens = -vgrad_T + k.kappa * Tv_r * om;               // P:230 (T_vadv == 0)
       double eta_lo = 0.0, eta_hi = 0.0;  // interface mass flux above / below this level
       if (VADV) {
@@ -442,11 +460,11 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         const double facp = half_rdp * eta_hi, facm = half_rdp * eta_lo;   // CaarFunctor.hpp:526-527
         const int ci = PP + t * 64 + lane;
         // CaarFunctor.hpp:513-546 (the zero rows of s_col stand in for the missing one-sided terms)
-        const double T_vadv = facp * (s_col[0][ci + PP] - T[r]) + facm * (T[r] - s_col[0][ci - PP]);
-        const double u_vadv = facp * (s_col[1][ci + PP] - u[r]) + facm * (u[r] - s_col[1][ci - PP]);
-        const double v_vadv = facp * (s_col[2][ci + PP] - v[r]) + facm * (v[r] - s_col[2][ci - PP]);
-        vtens1 = -u_vadv + v[r] * (fcor + vort) - gE0 - glnps1;     // X:326-328
-        vtens2 = -v_vadv - u[r] * (fcor + vort) - gE1 - glnps2;     // X:332-334
+        const double T_vadv = facp * (s_col[0][ci + PP] - T_r) + facm * (T_r - s_col[0][ci - PP]);
+        const double u_vadv = facp * (s_col[1][ci + PP] - u_r) + facm * (u_r - s_col[1][ci - PP]);
+        const double v_vadv = facp * (s_col[2][ci + PP] - v_r) + facm * (v_r - s_col[2][ci - PP]);
+        vtens1 = -u_vadv + v_r * (fcor + vort) - gE0 - glnps1;     // X:326-328
+        vtens2 = -v_vadv - u_r * (fcor + vort) - gE1 - glnps2;     // X:332-334
         ttens = -T_vadv - vgrad_T + k.kappa * Tv_r * om;           // X:338
       }
 
@@ -464,8 +482,8 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       stream_store<SNT>(phi_out + off, phi);                                        // P:294,303,309
       stream_store<ANT>(omega_p + off, cur.om + k.eta_ave_w * om);                  // P:173
       dbl2 vn;
-      vn.x = cur.vn0.x + k.eta_ave_w * (u[r] * dp[r]);              // P:117
-      vn.y = cur.vn0.y + k.eta_ave_w * (v[r] * dp[r]);              // P:118
+      vn.x = cur.vn0.x + k.eta_ave_w * (u_r * dp[r]);               // P:117
+      vn.y = cur.vn0.y + k.eta_ave_w * (v_r * dp[r]);               // P:118
       stream_store<ANT>(vn0 + off, vn);
       {
         const double e_new = cur.eta + (VADV ? k.eta_ave_w * eta_lo : eta_zero);  // P:172, X:271-272
@@ -503,7 +521,7 @@ template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, bool PERSI
 __global__ __launch_bounds__(NLEV_T ? (NLEV_T + 3) / 4 / TPW * 64 : DYNW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
   __shared__ Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW, PARK> lds;
   if constexpr (POL == 2) {
-    static_assert(!PERSIST && !VADV, "hybrid cache policy: plain vertically-Lagrangian form only");
+    static_assert(!PERSIST, "hybrid cache policy: non-persistent form only");
     const long long ie_s = element_of_block(k, blockIdx.x);
     if (ie_s < 0) return;
     if (element_is_cached(k, ie_s - k.nets))
@@ -527,10 +545,11 @@ static int cu_count() {
   return n;
 }
 
-// VTPW/VMINW/VPF: the launch shape of the Eulerian (rsplit == 0) form, which holds more live
-// values per level and wants fewer, fatter waves (tools/eulerian_bench.py).
+// VTPW/VMINW/VPF/VPARK: the launch shape of the Eulerian (rsplit == 0) form, which holds more live values per
+// level: the two-workgroup shapes need part of them parked in LDS (VPARK; bit 32 re-reads u, v, T from the column
+// copy the vertical advection keeps there anyway).  tools/eulerian_bench.py, tools/probes/eulerian_variants.py.
 template <int NLEV, int TPW, int MINW, int POL, int PF = 0, int PERSIST_WG_PER_CU = 0, bool ETA_COND = false,
-          int VTPW = TPW, int VMINW = MINW, int VPF = PF, int PARK = 0>
+          int VTPW = TPW, int VMINW = MINW, int VPF = PF, int PARK = 0, int VPARK = 0>
 static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = (NLEV + 3) / 4 / TPW * 64;
   constexpr bool PERSIST = PERSIST_WG_PER_CU > 0;
@@ -543,9 +562,9 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
     constexpr int VTHREADS = (NLEV + 3) / 4 / VTPW * 64;
     if (PERSIST) grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
     if (k.qn0 >= 0)
-      hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, true, (POL != 0), VPF, false, false, true>), dim3(grid), dim3(VTHREADS), 0, stream, k);
+      hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, true, POL, VPF, false, false, true, 8, VPARK>), dim3(grid), dim3(VTHREADS), 0, stream, k);
     else
-      hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, false, (POL != 0), VPF, false, false, true>), dim3(grid), dim3(VTHREADS), 0, stream, k);
+      hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, false, POL, VPF, false, false, true, 8, VPARK>), dim3(grid), dim3(VTHREADS), 0, stream, k);
     return hipGetLastError();
   }
   if (k.qn0 >= 0)
@@ -561,8 +580,8 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
-    {"caar_np4_kernel<72, 6, 1, true, 2, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU), hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<72, 6, 1, 2, 0, 0, false, 3, 2, 0>, true},
-    {"caar_np4_kernel<72, 6, 1, true, 1, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU), nt (all streaming), update loads one tile ahead", launch_np4<72, 6, 1, true, 0, 0, false, 3, 2, 0>},
+    {"caar_np4_kernel<72, 6, 1, true, 2, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU), hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<72, 6, 1, 2, 0, 0, false, 6, 2, 0, 0, 43>, true},
+    {"caar_np4_kernel<72, 6, 1, true, 1, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU), nt (all streaming), update loads one tile ahead", launch_np4<72, 6, 1, true, 0, 0, false, 6, 2, 0, 0, 43>},
     {"caar_np4_kernel<72, 2, 1, true, 2, 1, false, false, false, 8, 0>", "9 waves x 2 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<72, 2, 1, 2, 1, 0, false, 3, 2, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, false, false, 8, 0>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, true, false, 8, 0>", "9 waves x 2 tiles, nt; eta_dot_dpdn stored only where its bits change (skips the no-op write-back: NOT the contract traffic)", launch_np4<72, 2, 1, true, 1, 0, true, 3, 2, 0>},
@@ -579,8 +598,8 @@ KernelVariant kNp4Nlev72[] = {
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
-    {"caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS between the phases, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<128, 8, 2, 2, 0, 0, false, 8, 1, 0, 27>, true},
-    {"caar_np4_kernel<128, 8, 2, true, 1, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS, nt (all streaming), update loads one tile ahead", launch_np4<128, 8, 2, true, 0, 0, false, 8, 1, 0, 27>},
+    {"caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS between the phases, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<128, 8, 2, 2, 0, 0, false, 4, 2, 0, 27, 32>, true},
+    {"caar_np4_kernel<128, 8, 2, true, 1, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS, nt (all streaming), update loads one tile ahead", launch_np4<128, 8, 2, true, 0, 0, false, 4, 2, 0, 27, 32>},
     {"caar_np4_kernel<128, 4, 2, true, 2, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<128, 4, 2, 2, 1, 0, false, 8, 1, 0>},
     {"caar_np4_kernel<128, 4, 2, true, 1, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 1, 0>},
     {"caar_np4_kernel<128, 4, 2, true, 1, 0, false, false, false, 8, 0>", "8 waves x 4 tiles, nt, update loads one tile ahead", launch_np4<128, 4, 2, true, 0>},

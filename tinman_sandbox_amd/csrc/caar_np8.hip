@@ -98,8 +98,8 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   for (int r = 0; r < PD; ++r) ring[r] = load_n0(r);
   double T[RELOAD_T ? 1 : TPW], Tv[TPW];
   double* const park_dp = s_park + lev0 * PP + lane;  // + r*PP; u, v follow at BLK strides
-  // volatile reads: the compiler must not forward the parked values through registers
-  const volatile double* const park_rd = park_dp;
+  // re-reads through a laundered LDS pointer: the compiler must not forward the parked values through registers
+  const lds_cptr park_rd = lds_reread_ptr(park_dp);
   if (tid < 64) s_dvvT[(tid & 7) * NP + (tid >> 3)] = k.Dvv[tid];  // Dvv[k][j] -> dvvT[j][k]
   if (VADV && tid < PP) s_park[3 * BLK + tid] = 0.0;
   for (int idx = tid; idx < G_SIZE; idx += THREADS) {
@@ -248,9 +248,9 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     if (r + LA < TPW) ahead[r % LA] = load_level(r + LA);
 
     // The metric terms are re-read from LDS at every level instead of living in 26 registers
-    // for the whole phase; the empty asm makes the pointer opaque so the loads are not hoisted.
-    const double* geo = s_geo;
-    asm volatile("" : "+v"(geo));
+    // for the whole phase; the pointer is made opaque (but stays an LDS pointer: ds_read, not flat_load, which would
+    // queue behind the outstanding global loads) so the loads are not hoisted.
+    const lds_cptr geo = lds_reread_ptr(s_geo);
     const M22 Dinv = load_m22(geo + G_DINV, pt);
     const double phis = geo[G_PHIS + pt];
     const double dpr = park_rd[r * PP], ur = park_rd[BLK + r * PP], vr = park_rd[2 * BLK + r * PP];

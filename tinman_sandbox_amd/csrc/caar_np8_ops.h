@@ -75,7 +75,8 @@ __device__ __forceinline__ void put_tile(const Ctx& c, int lane, double f) {
 struct M22 {
   double m00, m01, m10, m11;
 };
-__device__ __forceinline__ M22 load_m22(const double* g, int pt) {
+template <class Ptr>  // const double* or lds_cptr
+__device__ __forceinline__ M22 load_m22(Ptr g, int pt) {
   M22 m;
   m.m00 = g[pt * 4 + 0];
   m.m01 = g[pt * 4 + 1];

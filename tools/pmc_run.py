@@ -21,6 +21,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--np", type=int, default=4, dest="np_")
 ap.add_argument("--nlev", type=int, default=72)
 ap.add_argument("--elems", type=int, default=10000)
+ap.add_argument("--rsplit", type=int, default=1, help="0: the Eulerian form (eta_dot_dpdn, vertical advection)")
 a = ap.parse_args()
 L = tsa.library()
 lib = L.lib
@@ -42,6 +43,10 @@ if a.np_ == 4:
         L.check(lib.caar_traffic_skeleton(C.byref(dims), C.byref(ptrs), C.byref(prm), 0, C.c_void_p(st.cuda_stream)), "skel")
     torch.cuda.synchronize()
     data = tsa.TestData().init_data(a.elems, a.np_, a.nlev, device=dev)
+if a.rsplit == 0:
+    import numpy as np
+    data.hvcoord.hybi = (np.arange(a.nlev + 1) / a.nlev) ** 2
+    data.control.rsplit = 0
 for _ in range(5):
     tsa.compute_and_apply_rhs(data, st)
 torch.cuda.synchronize()
