@@ -495,9 +495,9 @@ struct HostOpScratch {
     return e;
   }
 };
-HostOpScratch& host_op_scratch() {
+HostOpScratch* host_op_scratch() {  // (a pointer: this sits inside the extern "C" block)
   static HostOpScratch* s = new HostOpScratch();  // never destroyed: no HIP calls from static destructors at exit
-  return *s;
+  return s;
 }
 }  // namespace
 
@@ -510,7 +510,7 @@ int caar_sphere_operator_host(const CaarDims* dims, const CaarArrays* host, cons
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CAAR_ENODEVICE;
   const size_t pp = (size_t)dims->np * dims->np, nin = which == 0 ? pp : 2 * pp, nout = which == 0 ? 2 * pp : pp;
-  HostOpScratch& s = host_op_scratch();
+  HostOpScratch& s = *host_op_scratch();
   std::lock_guard<std::mutex> g(s.mu);
   double* d = nullptr;
   HIP_TRY(s.area(pp * 11 + nin + nout, &d));
@@ -546,7 +546,7 @@ int caar_preq_hydrostatic_host(const CaarDims* dims, const double* phis, const d
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CAAR_ENODEVICE;
   const size_t pp = (size_t)dims->np * dims->np, blk = pp * dims->nlev;
-  HostOpScratch& s = host_op_scratch();
+  HostOpScratch& s = *host_op_scratch();
   std::lock_guard<std::mutex> g(s.mu);
   double* d = nullptr;
   HIP_TRY(s.area(pp + 4 * blk, &d));
@@ -566,7 +566,7 @@ int caar_preq_omega_ps_host(const CaarDims* dims, const double* p, const double*
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CAAR_ENODEVICE;
   const size_t pp = (size_t)dims->np * dims->np, blk = pp * dims->nlev;
-  HostOpScratch& s = host_op_scratch();
+  HostOpScratch& s = *host_op_scratch();
   std::lock_guard<std::mutex> g(s.mu);
   double* d = nullptr;
   HIP_TRY(s.area(4 * blk, &d));
