@@ -289,17 +289,21 @@ def test_half_the_hbm_in_one_launch(oracle):
     torch.cuda.empty_cache()
 
 
-def test_cache_window_changes_nothing_but_speed():
+@pytest.mark.parametrize("nlev,rsplit", [(72, 1), (72, 0), (128, 1), (128, 0)])
+def test_cache_window_changes_nothing_but_speed(nlev, rsplit):
     """caar_set_cache_window: which elements keep their accumulators in the Infinity Cache is a
-    cache-policy choice; every setting must give bit-identical arrays."""
+    cache-policy choice; every setting must give bit-identical arrays — in the Lagrangian and the Eulerian form
+    (both run the hybrid policy by default), windows that keep none, some and all of the elements."""
     lib = tsa.library().lib
-    arrs = cases.hashed_arrays(4, 72, 37, seed=251)
+    arrs = cases.hashed_arrays(4, nlev, 37, seed=251 + nlev)
     Dvv = cases.dvv_for(4)
-    sc = po.default_scalars(72)
+    sc = po.default_scalars(nlev)
     sc.update(qn0=1, dt2=0.5, nets=2, nete=35)
+    if rsplit == 0:
+        sc.update(rsplit=0, hybi=(np.arange(nlev + 1) / nlev) ** 2)
     ref = None
     try:
-        for window in (192 << 20, 0, 1 << 16, 300 * 1024, 1 << 40):
+        for window in (192 << 20, 0, 1 << 16, 300 * 1024, 700 * 1024, 1 << 40):
             assert lib.caar_set_cache_window(window) == 0
             data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
             tsa.compute_and_apply_rhs(data)
