@@ -56,10 +56,11 @@ __device__ __forceinline__ void scan_up(double x, int lane, int sub, double& inc
   excl = sub <= 2 ? t : 0.0;
 }
 
-// Workgroup barrier.  __syncthreads() also drains the wave's global-memory counter
-// (s_waitcnt vmcnt(0)); in the persistent form that would stall every barrier on the previous
-// element's stores, so there only the LDS counter is drained — the barriers order LDS
-// traffic, all global data is wave-private.
+// Workgroup barrier.  __syncthreads() is a workgroup-scope fence + s_barrier: with global stores outstanding
+// the fence waits for them too (s_waitcnt vmcnt(0)); in the persistent form that would stall every barrier on
+// the previous element's stores, so there only the LDS counter is drained — the barriers order LDS traffic,
+// all global data is wave-private.  (In the non-persistent kernels no store precedes a barrier and the compiled
+// barriers are `s_waitcnt lgkmcnt(0); s_barrier`: loads requested before a barrier stay in flight across it.)
 template <bool LDS_ONLY>
 __device__ __forceinline__ void wg_barrier() {
   if constexpr (LDS_ONLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
