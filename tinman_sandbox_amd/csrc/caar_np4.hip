@@ -276,7 +276,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     if (PERSIST) {
       if (tid < G_SIZE) s_geo[tid] = geo_reg;
     } else {
-      for (int idx = tid; idx < G_SIZE; idx += THREADS) s_geo[idx] = *geo_src(ie, idx);
+      for (int idx = tid; idx < G_SIZE; idx += THREADS) s_geo[idx] = stream_load<SNT>(geo_src(ie, idx));
     }
     wg_barrier<PERSIST>();  // also fences the previous element's last reads of the tile totals
 

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     else if (idx < G_D) src = k.phis + ie * PP + (idx - G_PHIS);
     else if (idx < G_DINV) src = k.D + ie * PP * 4 + (idx - G_D);
     else src = k.Dinv + ie * PP * 4 + (idx - G_DINV);
-    s_geo[idx] = *src;
+    s_geo[idx] = stream_load<SNT>(src);
   }
   __syncthreads();
 
