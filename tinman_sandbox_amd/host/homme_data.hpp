@@ -34,64 +34,49 @@ constexpr int timelevels = CAAR_NUM_TIME_LEVELS;
 
 extern int num_elems;  // set by the driver before init_data (reference: main.cpp:11)
 
+// hybrid vertical coordinate: only ps0 and hyai(1) enter the path (data_structures.hpp:10-16)
 struct HVCoord {
-  real ps0;
-  real hyai[nlevp];
+  real ps0, hyai[nlevp];
   void init_data();
 };
 
-// 16 element-major arrays; member order is part of the interface (include/caar.h CaarArrays)
+// The 16 element-major arrays.  Member ORDER is part of the interface: include/caar.h's CaarArrays is read
+// as this struct (and as the reference's, data_structures.hpp:18-44).
 struct Arrays {
-  real* elem_D;
-  real* elem_Dinv;
-  real* elem_fcor;
-  real* elem_spheremp;
-  real* elem_metdet;
-  real* elem_rmetdet;
+  real *elem_D, *elem_Dinv;                                          // [ie][np][np][2][2]
+  real *elem_fcor, *elem_spheremp, *elem_metdet, *elem_rmetdet;      // [ie][np][np]
+  real *elem_state_dp3d;                                             // [ie][timelevels][nlev][np][np]
+  real *elem_state_v;                                                // [ie][timelevels][nlev][np][np][2]
+  real *elem_state_T;                                                // as dp3d
+  real *elem_state_phis;                                             // [ie][np][np]
+  real *elem_state_Qdp;                                              // [ie][qsize_d][2][nlev][np][np]
+  real *elem_derived_eta_dot_dpdn;                                   // [ie][nlevp][np][np]
+  real *elem_derived_omega_p, *elem_derived_phi, *elem_derived_pecnd;  // [ie][nlev][np][np]
+  real *elem_derived_vn0;                                            // [ie][nlev][np][np][2]
 
-  real* elem_state_dp3d;
-  real* elem_state_v;
-  real* elem_state_T;
-  real* elem_state_phis;
-  real* elem_state_Qdp;
-
-  real* elem_derived_eta_dot_dpdn;
-  real* elem_derived_omega_p;
-  real* elem_derived_phi;
-  real* elem_derived_pecnd;
-  real* elem_derived_vn0;
-
-  void init_data();
-  void cleanup_data();
+  void init_data();     // new[] + the reference's closed-form values (data_structures.cpp:14-92)
+  void cleanup_data();  // drops the shim's page locks, then frees
 };
 
-struct Constants {
-  real rrearth;
-  real eta_ave_w;
-  real cp;
-  real Rwater_vapor;
-  real Rgas;
-  real kappa;
+struct Constants {  // data_structures.hpp:46-56
+  real rrearth, eta_ave_w, cp, Rwater_vapor, Rgas, kappa;
   void init_data();
 };
 
-struct Control {
-  int nets;
-  int nete;
-  int n0;
-  int np1;
-  int nm1;
-  int qn0;
+struct Control {  // data_structures.hpp:58-69
+  int nets, nete;     // element range [nets, nete)
+  int n0, np1, nm1;   // time levels
+  int qn0;            // tracer time level, -1 = dry
   real dt2;
   void init_data();
 };
 
-struct Derivative {
+struct Derivative {  // data_structures.hpp:71-76
   real Dvv[np][np];
   void init_data();
 };
 
-struct TestData {
+struct TestData {  // data_structures.hpp:78-89
   Arrays arrays = {};
   Constants constants = {};
   Control control = {};
