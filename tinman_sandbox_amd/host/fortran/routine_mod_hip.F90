@@ -1,0 +1,138 @@
+! routine_mod_hip.F90 -- link-level replacement of the reference's Fortran hot path.
+!
+! Same module name, same subroutine, same argument list as
+!     compute_and_apply_rhs_test/fortran/routine_mod.F90:7
+!     subroutine compute_and_apply_rhs(np1,nm1,n0,qn0,dt2,elem,hvcoord,deriv,nets,nete,eta_ave_w)
+! compiled against the reference's OWN modules (kinds, element_mod, derivative_mod_base, hybvcoord_mod,
+! physical_constants), so the reference's main.F90 builds and runs unchanged with this file in the place of
+! routine_mod.F90 (+ caar_mod.F90 and -lcaar_hip on the link line; INTEGRATION.md section 4, oracle/Makefile target
+! fortran_orig_hip).  The work is done by libcaar_hip.so on the MI355X.
+!
+! The reference keeps its fields inside the derived type, elem(ie)%state%v(np,np,2,nlev,timelevels) etc.
+! (element_state_mod.F90:17-23, element_mod.F90:63-121): one struct per element, so the fields of different elements
+! are not contiguous.  Every call therefore gathers the sixteen arrays of elements nets..nete into flat
+! Fortran-ordered arrays (the layout caar_upload_f90 takes), runs, and scatters back what the path mutates:
+! state%v/T/dp3d at np1, derived%vn0/omega_p/eta_dot_dpdn/phi.  Host semantics are the reference's; a host that steps
+! in a loop and wants the data to stay on the GPU uses caar_mod directly (caar_f90_driver.F90).
+module routine_mod
+  use iso_c_binding
+  use caar_mod
+  implicit none
+  private
+  public :: compute_and_apply_rhs
+
+  type(c_ptr), save :: ctx = c_null_ptr
+  integer, save :: ctx_elems = 0
+  real(c_double), allocatable, target, save :: gD(:,:,:,:,:), gDinv(:,:,:,:,:)
+  real(c_double), allocatable, target, save :: gfcor(:,:,:), gspheremp(:,:,:), gmetdet(:,:,:), grmetdet(:,:,:), gphis(:,:,:)
+  real(c_double), allocatable, target, save :: gdp3d(:,:,:,:,:), gT(:,:,:,:,:), gv(:,:,:,:,:,:), gQdp(:,:,:,:,:,:)
+  real(c_double), allocatable, target, save :: geta(:,:,:,:), gomega(:,:,:,:), gphi(:,:,:,:), gpecnd(:,:,:,:), gvn0(:,:,:,:,:)
+  real(c_double), target, save :: Dvv_c(64)
+
+contains
+
+  subroutine compute_and_apply_rhs(np1,nm1,n0,qn0,dt2,elem,hvcoord,deriv,nets,nete,eta_ave_w)
+    use kinds, only : real_kind, np, nlev, timelevels, qsize_d
+    use element_mod, only : element_t
+    use derivative_mod_base, only : derivative_t
+    use hybvcoord_mod, only : hvcoord_t
+    use physical_constants, only : Rgas, Rwater_vapor, kappa, rrearth
+
+    type (element_t), intent(inout), target :: elem(:)
+    type (derivative_t), intent(in) :: deriv
+    type (hvcoord_t), intent(in) :: hvcoord
+    integer, intent(in) :: nets, nete, np1, nm1, n0, qn0
+    real*8, intent(in) :: dt2
+    real (kind=real_kind), intent(in) :: eta_ave_w
+
+    type(caar_arrays_t) :: a
+    type(caar_params_t) :: prm
+    integer :: ie, ne, i, j
+
+    ne = size(elem)
+    if (ne /= ctx_elems) call resize(ne, np, nlev, timelevels, qsize_d)
+
+    ! gather (first index fastest, element last: the layout of include/caar.h "Fortran-layout ingest / egress")
+    do ie = nets, nete
+      gD(:,:,:,:,ie) = elem(ie)%D
+      gDinv(:,:,:,:,ie) = elem(ie)%Dinv
+      gfcor(:,:,ie) = elem(ie)%fcor
+      gspheremp(:,:,ie) = elem(ie)%spheremp
+      gmetdet(:,:,ie) = elem(ie)%metdet
+      grmetdet(:,:,ie) = elem(ie)%rmetdet
+      gphis(:,:,ie) = elem(ie)%state%phis
+      gdp3d(:,:,:,:,ie) = elem(ie)%state%dp3d
+      gT(:,:,:,:,ie) = elem(ie)%state%T
+      gv(:,:,:,:,:,ie) = elem(ie)%state%v
+      ! the path reads one tracer time level, Qdp(:,:,:,1,qn0) (routine_mod.F90:99-113): it travels as slot 1
+      if (qn0 >= 1) gQdp(:,:,:,:,1,ie) = elem(ie)%state%Qdp(:,:,:,:,qn0)
+      geta(:,:,:,ie) = elem(ie)%derived%eta_dot_dpdn
+      gomega(:,:,:,ie) = elem(ie)%derived%omega_p
+      gphi(:,:,:,ie) = elem(ie)%derived%phi
+      gpecnd(:,:,:,ie) = elem(ie)%derived%pecnd
+      gvn0(:,:,:,:,ie) = elem(ie)%derived%vn0
+    end do
+
+    a%elem_D = c_loc(gD); a%elem_Dinv = c_loc(gDinv); a%elem_fcor = c_loc(gfcor); a%elem_spheremp = c_loc(gspheremp)
+    a%elem_metdet = c_loc(gmetdet); a%elem_rmetdet = c_loc(grmetdet)
+    a%elem_state_dp3d = c_loc(gdp3d); a%elem_state_v = c_loc(gv); a%elem_state_T = c_loc(gT)
+    a%elem_state_phis = c_loc(gphis); a%elem_state_Qdp = c_loc(gQdp)
+    a%elem_derived_eta_dot_dpdn = c_loc(geta); a%elem_derived_omega_p = c_loc(gomega)
+    a%elem_derived_phi = c_loc(gphi); a%elem_derived_pecnd = c_loc(gpecnd); a%elem_derived_vn0 = c_loc(gvn0)
+
+    do i = 1, np   ! C order: Dvv_c((i-1)*np + j) = deriv%Dvv(i,j)
+      do j = 1, np
+        Dvv_c((i-1)*np + j) = deriv%Dvv(i,j)
+      end do
+    end do
+
+    ! 1-based inclusive nets..nete and time levels -> 0-based [nets-1, nete)
+    prm%nets = nets - 1; prm%nete = nete
+    prm%n0 = n0 - 1; prm%np1 = np1 - 1; prm%nm1 = nm1 - 1
+    prm%qn0 = merge(0, -1, qn0 >= 1)            ! -1: dry (routine_mod.F90:95-98)
+    prm%dt2 = dt2; prm%eta_ave_w = eta_ave_w
+    prm%rrearth = rrearth; prm%Rwater_vapor = Rwater_vapor; prm%Rgas = Rgas; prm%kappa = kappa
+    prm%ps0 = hvcoord%ps0; prm%hyai0 = hvcoord%hyai(1)
+    prm%Dvv = c_loc(Dvv_c)
+
+    call caar_check(caar_upload_f90(ctx, a, int(nets - 1, c_int), int(nete, c_int)), 'caar_upload_f90')
+    call caar_check(caar_run(ctx, prm), 'caar_run')
+    call caar_check(caar_download_f90(ctx, a, int(nets - 1, c_int), int(nete, c_int), 0_c_int), 'caar_download_f90')
+    call caar_check(caar_sync(ctx), 'caar_sync')
+
+    ! scatter what the path mutates (routine_mod.F90:79-190)
+    do ie = nets, nete
+      elem(ie)%state%v(:,:,:,:,np1) = gv(:,:,:,:,np1,ie)
+      elem(ie)%state%T(:,:,:,np1) = gT(:,:,:,np1,ie)
+      elem(ie)%state%dp3d(:,:,:,np1) = gdp3d(:,:,:,np1,ie)
+      elem(ie)%derived%vn0 = gvn0(:,:,:,:,ie)
+      elem(ie)%derived%omega_p = gomega(:,:,:,ie)
+      elem(ie)%derived%eta_dot_dpdn = geta(:,:,:,ie)
+      elem(ie)%derived%phi = gphi(:,:,:,ie)
+    end do
+  end subroutine compute_and_apply_rhs
+
+  ! (re)creates the device context and the staging arrays for ne elements
+  subroutine resize(ne, np, nlev, timelevels, qsize_d)
+    integer, intent(in) :: ne, np, nlev, timelevels, qsize_d
+    type(caar_dims_t) :: dims
+    if (caar_supported(int(np, c_int), int(nlev, c_int)) /= 1) then
+      print *, 'caar: no MI355X kernel for np, nlev = ', np, nlev
+      error stop 1
+    end if
+    if (c_associated(ctx)) then
+      call caar_destroy(ctx)
+      deallocate(gD, gDinv, gfcor, gspheremp, gmetdet, grmetdet, gphis, gdp3d, gT, gv, gQdp, geta, gomega, gphi, gpecnd, gvn0)
+    end if
+    allocate(gD(np,np,2,2,ne), gDinv(np,np,2,2,ne))
+    allocate(gfcor(np,np,ne), gspheremp(np,np,ne), gmetdet(np,np,ne), grmetdet(np,np,ne), gphis(np,np,ne))
+    allocate(gdp3d(np,np,nlev,timelevels,ne), gT(np,np,nlev,timelevels,ne), gv(np,np,2,nlev,timelevels,ne))
+    allocate(gQdp(np,np,nlev,qsize_d,2,ne))
+    allocate(geta(np,np,nlev+1,ne), gomega(np,np,nlev,ne), gphi(np,np,nlev,ne), gpecnd(np,np,nlev,ne), gvn0(np,np,2,nlev,ne))
+    gQdp = 0.0d0
+    dims%np = np; dims%nlev = nlev; dims%qsize_d = qsize_d; dims%timelevels = timelevels; dims%num_elems = ne
+    call caar_check(caar_create(ctx, dims, 0_c_int), 'caar_create')
+    ctx_elems = ne
+  end subroutine resize
+
+end module routine_mod
