@@ -14,6 +14,8 @@
 ! Fortran-ordered arrays (the layout caar_upload_f90 takes), runs, and scatters back what the path mutates:
 ! state%v/T/dp3d at np1, derived%vn0/omega_p/eta_dot_dpdn/phi.  Host semantics are the reference's; a host that steps
 ! in a loop and wants the data to stay on the GPU uses caar_mod directly (caar_f90_driver.F90).
+! Called from one thread at a time, as the reference's main.F90 does (its OpenMP is inside the routine, over levels:
+! routine_mod.F90:76-137); the device context and the staging arrays are module state, created on first use.
 module routine_mod
   use iso_c_binding
   use caar_mod
