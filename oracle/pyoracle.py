@@ -342,15 +342,17 @@ class Reference:
         return self.lib.ref_compute_norm(_ptr(f), f.size)
 
 
-def run_fortran_driver(arrs, Dvv, sc, native=False):
+def run_fortran_driver(arrs, Dvv, sc, native=False, exe_name="fortran_driver"):
     """Run oracle/_ref/fortran_driver (reference Fortran routine_mod, NP=4 NLEV=72,
     physical constants fixed by physical_constants.F90) on `arrs`; returns the
     mutated arrays.  `arrs` itself is left untouched.  native=True returns instead a
     dict with "c_<name>" (C++ layout, via the driver's explicit index loops) and
     "f_<name>" (the same array in Fortran's native element order, shaped as a C-ordered
-    array with the Fortran first index last) for the layout-kernel fixtures."""
+    array with the Fortran first index last) for the layout-kernel fixtures.
+    exe_name="fortran_driver_hip": the same driver program linked against the HIP drop-in module
+    (host/fortran/routine_mod_hip.F90) instead of the reference's routine_mod — the thing under test then."""
     import tempfile
-    exe = os.path.join(HERE, "_ref", "fortran_driver")
+    exe = os.path.join(HERE, "_ref", exe_name)
     ne, tl, nlev, np_, _ = arrs["elem_state_dp3d"].shape
     with tempfile.TemporaryDirectory() as td:
         fin, fout, fnat = os.path.join(td, "in.bin"), os.path.join(td, "out.bin"), os.path.join(td, "nat.bin")

@@ -141,6 +141,35 @@ def test_reference_fortran_main_links_against_the_hip_path():
     assert np.allclose(got[3:], want[3:], rtol=1e-13, atol=0)
 
 
+FORTRAN_CASES = [n for n in cases.CASES
+                 if os.path.exists(cases.golden_path(n)) and "f90_elem_state_T" in np.load(cases.golden_path(n)).files]
+
+
+@pytest.mark.parametrize("name", FORTRAN_CASES)
+def test_fortran_dropin_module_matches_the_reference_routine(name):
+    """host/fortran/routine_mod_hip.F90 (module routine_mod, the reference's compute_and_apply_rhs argument list on
+    the reference's derived types) under oracle/ref_fortran_driver.F90 — the program that produced the f90_* fixtures
+    with the REFERENCE's routine_mod: same program, same input file, the drop-in module instead.  Every array the path
+    mutates (dp3d, v, T at np1; eta_dot_dpdn, omega_p, phi, vn0) must equal what the reference's Fortran routine wrote,
+    <= 1e-12; untouched time levels must come back unchanged (the module scatters only np1)."""
+    from oracle import pyoracle as po
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "fortran_driver_hip")):
+        pytest.skip("oracle/_ref/fortran_driver_hip is only built where /root/reference exists")
+    arrs, Dvv, sc = cases.make_case(name)
+    scf = dict(sc)
+    scf["nets"], scf["nete"] = 0, None  # the driver program runs every element
+    got = po.run_fortran_driver(arrs, Dvv, scf, exe_name="fortran_driver_hip")
+    gold = cases.load_golden(name)
+    for n in cases.OUTPUT_NAMES:
+        w = gold["f90_" + n]
+        g = got[n][:, sc["np1"]] if n.startswith("elem_state_") else got[n]
+        assert cases.scaled_err(g, w) <= 1e-12, (name, n, cases.scaled_err(g, w))
+        if n.startswith("elem_state_"):
+            for tl in range(arrs[n].shape[1]):
+                if tl != sc["np1"]:
+                    assert np.array_equal(got[n][:, tl], arrs[n][:, tl]), (name, n, tl)
+
+
 def test_reference_main_links_against_the_hip_path():
     exe = os.path.join(ROOT, "oracle", "_ref", "pointers_only_hip")
     if not os.path.exists(exe):
