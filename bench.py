@@ -50,6 +50,9 @@ def parse():
                     help="also time 20 launches one by one (roofline.kernel_ms_isolated_*)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short extra measurements of BASELINE.json configs[3] and [4]")
+    ap.add_argument("--no-interleaved", action="store_true",
+                    help="skip the host-sequence measurements (roofline.interleaved: CAAR alternated with a tracer step / "
+                         "a cache-evicting kernel, time levels rotating)")
     ap.add_argument("--no-spinup", action="store_true",
                     help="skip the untimed device spin-up before the W warmup steps: the timed steps then run on a "
                          "device that is still ramping up (fresh process: clocks, TLBs, cache window; ~25 ms)")
@@ -143,7 +146,7 @@ def measure_config(np_, nlev, elems, steps, warmup):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--np", str(np_), "--nlev", str(nlev),
            "--elems-per-gpu", str(elems), "--steps", str(steps), "--warmup", str(warmup), "--no-other-configs",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--no-interleaved"]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
@@ -271,11 +274,7 @@ def placement_spread(tsa, torch, args, data, dev, stream, mine, nets):
     out = []
     others = [tsa.TestData().init_data(mine, args.np_, args.nlev, device=dev, first_elem=nets) for _ in range(2)]
     # ... and on torch's own sixteen allocations (what round 1 measured on), last in the list
-    os.environ["CAAR_PLACEMENT"] = "torch"
-    try:
-        others.append(tsa.TestData().init_data(mine, args.np_, args.nlev, device=dev, first_elem=nets))
-    finally:
-        del os.environ["CAAR_PLACEMENT"]
+    others.append(tsa.TestData().init_data(mine, args.np_, args.nlev, device=dev, first_elem=nets, place="torch"))
     for d in [data] + others:
         time_launches(tsa, torch, d, stream, dev, 20, 40)
         # best of three blocks: a block is occasionally hit by a stall of tens of ms (the driver wiping memory freed
@@ -283,6 +282,89 @@ def placement_spread(tsa, torch, args, data, dev, stream, mine, nets):
         ms = min(time_launches(tsa, torch, d, stream, dev, 20, 0) for _ in range(3))
         out.append(balg_of(tsa, args) * mine / (ms * 1e-3) / 1e9)
     del others
+    torch.cuda.empty_cache()
+    return out
+
+
+def interleaved_sequences(tsa, torch, args, data, dev, stream, mine, steps):
+    """What a time-stepping HOST gets, as opposed to bench.py's replay loop: compute_and_apply_rhs alternated with other
+    work on the same elements, with TestData::update_time_levels between the steps (the reference's driver loop with its
+    commented-out rotation, main.cpp:113-121, :118).  Two neighbours are measured:
+      * "euler_step": caar_euler_step with 4 tracers on the same elements (EulerStepFunctor.hpp:32-68; this library's own
+        kernel, all accesses non-temporal: 0.92 GB of traffic per call at 10 000 elements, none of it allocating in the
+        Infinity Cache);
+      * "evicting": a foreign kernel with the default cache policy that moves 768 MiB (torch.add on 256 MiB operands) —
+        three times the Infinity Cache, so whatever the CAAR kernel left there is gone when it runs again.
+    The CAAR time inside a sequence is (time of K steps of the sequence - time of K calls of the neighbour alone) / K: all
+    interference is charged to CAAR.  Every sequence is run with the default kernel and with its all-streaming twin
+    (variant 1), so the line shows what the cache window is worth under each host pattern.  Outside the timed region of
+    `value`."""
+    import ctypes as C
+    L = tsa.library()
+    lib = L.lib
+    np_, nlev = args.np_, args.nlev
+    f64 = torch.float64
+    qsize = 4
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    vstar = torch.rand((mine, nlev, np_, np_, 2), dtype=f64, device=dev, generator=g)
+    qdp4 = torch.rand((mine, qsize, 2, nlev, np_, np_), dtype=f64, device=dev, generator=g)
+    qtens = torch.empty((mine, qsize, nlev, np_, np_), dtype=f64, device=dev)
+    geo = {n: data.arrays["elem_" + n] for n in ("Dinv", "metdet", "rmetdet")}
+    dvv = data.dvv_device()
+    n_ev = 1 << 25  # 256 MiB per operand
+    ev_a = torch.ones(n_ev, dtype=f64, device=dev)
+    ev_b = torch.ones(n_ev, dtype=f64, device=dev)
+    ev_c = torch.empty(n_ev, dtype=f64, device=dev)
+    neighbours = {
+        "euler_step": (lambda: tsa.euler_step(vstar, qdp4, geo, dvv, qsize, 0, 0.01, data.constants.rrearth, out=qtens),
+                       "caar_euler_step, 4 tracers, same elements (nt accesses, %.2f GB per call)" % (
+                           (vstar.numel() + qdp4.numel() // 2 + qtens.numel()) * 8 / 1e9)),
+        "evicting": (lambda: torch.add(ev_a, ev_b, out=ev_c),
+                     "torch.add on three 256 MiB arrays (default cache policy, 0.81 GB per call: evicts the Infinity Cache)"),
+    }
+    saved = (data.control.n0, data.control.np1, data.control.nm1)
+
+    def timed(fn, n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(n):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / n
+
+    def step_with(other):
+        def f():
+            tsa.compute_and_apply_rhs(data, stream)
+            other()
+            data.update_time_levels()
+        return f
+
+    balg_launch = tsa.algorithmic_bytes(np_, nlev) * mine
+    out = {}
+    have_twin = np_ == 4 and lib.caar_num_variants(np_, nlev) > 1
+    try:
+        for name, (other, what) in neighbours.items():
+            timed(other, 5)
+            other_ms = min(timed(other, steps) for _ in range(2))
+            row = {"neighbour": what, "neighbour_ms": other_ms, "steps": steps}
+            for label, variant in (("default", 0), ("all_streaming", 1)):
+                if variant and not have_twin:
+                    continue
+                lib.caar_select_variant(np_, nlev, variant)
+                seq = step_with(other)
+                timed(seq, 10)
+                seq_ms = min(timed(seq, steps) for _ in range(2))
+                caar_ms = seq_ms - other_ms
+                row[label] = {"sequence_ms": seq_ms, "caar_ms": caar_ms, "achieved": balg_launch / (caar_ms * 1e-3) / 1e9,
+                              "frac": balg_launch / (caar_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "kernel": lib.caar_kernel_name(np_, nlev).decode()}
+            out[name] = row
+    finally:
+        lib.caar_select_variant(np_, nlev, 0)
+        data.control.n0, data.control.np1, data.control.nm1 = saved
+    del vstar, qdp4, qtens, ev_a, ev_b, ev_c
     torch.cuda.empty_cache()
     return out
 
@@ -353,13 +435,18 @@ def main():
         tsa.compute_and_apply_rhs(data, stream)
     ev1.record(stream)
     torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0          # this rank's K steps, start barrier to its own last step done
     barrier()
     torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
+    wall_with_barrier = time.perf_counter() - t0  # ... plus the closing barrier (collective latency, not step time)
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
 
     from tinman_sandbox_amd import sharding
-    wall_max, kernel_ms_max = sharding.max_over_ranks([wall, kernel_ms], dist, reduce_dev)
+    # the job is done when its slowest rank is: MAX over ranks of each rank's own time for the K steps.  All ranks leave
+    # the opening barrier together; the closing barrier's own latency (tens of microseconds to milliseconds over 8 ranks,
+    # against ~8 ms of timed steps) is reported beside it, not charged to the steps.
+    wall_max, kernel_ms_max, wall_with_barrier_max = sharding.max_over_ranks([wall, kernel_ms, wall_with_barrier], dist,
+                                                                             reduce_dev)
     per_rank = sharding.gather_over_ranks([float(mine), kernel_ms], dist, reduce_dev)  # [[elems, ms], ...]
 
     # The default NP=4 kernels keep the read-modify-write accumulators of part of the elements in the
@@ -444,7 +531,15 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            # what actually ran before the timed region: the first-use launch, the untimed spin-up to the steady state
+            # (see spin_up; --no-spinup: none) and the W warmup steps
+            "warmup_effective": 1 + 20 * len(spin) + args.warmup,
             "ms_per_step": wall_max / args.steps * 1e3,
+            "ms_per_step_incl_closing_barrier": wall_with_barrier_max / args.steps * 1e3,
+            # how the ranks were coupled: the torch.distributed backend ("nccl" is RCCL on ROCm; "gloo" only in the
+            # one-GPU rehearsal mode CAAR_BENCH_BACKEND=gloo) and the world size the process group reports
+            "backend": (dist.get_backend() if dist is not None else "none"),
+            "dist_world_size": (dist.get_world_size() if dist is not None else 1),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -470,6 +565,15 @@ def main():
             # (the headline arrays stay allocated: freeing and re-allocating them would change what placement_spread sees)
             out["other_configs"] = [measure_config(4, 72, 12500, 20, 5), measure_config(4, 128, 12500, 20, 5),
                                     measure_config(8, 72, 20000, 10, 3)]
+        if world == 1 and not args.no_interleaved:
+            seqs = interleaved_sequences(tsa, torch, args, data, dev, stream, mine, args.steps)
+            roof["interleaved"] = seqs
+            # CAAR inside the reference's driver loop with rotation and a tracer step between the calls ...
+            roof["achieved_interleaved"] = seqs["euler_step"]["default"]["achieved"]
+            roof["frac_interleaved"] = seqs["euler_step"]["default"]["frac"]
+            # ... and with a neighbour that wipes the Infinity Cache between the calls
+            roof["achieved_interleaved_evicting"] = seqs["evicting"]["default"]["achieved"]
+            roof["frac_interleaved_evicting"] = seqs["evicting"]["default"]["frac"]
         if world == 1 and not args.no_other_configs:
             # the same step on [the timed allocation, two more placed allocations, plain torch allocations] (GB/s)
             roof["placement_spread_achieved"] = placement_spread(tsa, torch, args, data, dev, stream, mine, nets)

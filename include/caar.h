@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAAR_ABI_VERSION 3
+#define CAAR_ABI_VERSION 4
 
 enum {
   CAAR_OK = 0,
@@ -132,6 +132,13 @@ long long caar_algorithmic_bytes(int np, int nlev, int dry);
  * synchronisation, safe to capture in a hipGraph. */
 int caar_launch(const CaarDims *dims, const CaarArrays *dev, const double *dvv_dev,
                 const CaarParams *params, void *stream);
+
+/* `nsteps` consecutive calls (the driver loop main.cpp:113-121), with TestData::update_time_levels
+ * (data_structures.cpp:174-180: np1, nm1, n0 <- nm1, n0, np1) between them if rotate != 0, on device-resident arrays:
+ * one kernel launch where the selected variant has a step-loop kernel (see caar_set_fused_steps), else nsteps launches
+ * of caar_launch.  Same arguments and rules as caar_launch; bit-identical to nsteps calls of it. */
+int caar_launch_steps(const CaarDims *dims, const CaarArrays *dev, const double *dvv_dev, const CaarParams *params,
+                      int nsteps, int rotate, void *stream);
 
 /* The three sphere operators on their own (reference: sphere_operators.hpp:9-16,
  * gradient_sphere / divergence_sphere / vorticity_sphere(field, data, ielem, out)), batched
@@ -319,12 +326,34 @@ int caar_traffic_skeleton(const CaarDims *dims, const CaarArrays *dev, const Caa
  * Where the arrays lie in HBM matters on MI355X: device memory falls into a few large address classes and the path runs
  * 3-5 % faster when its traffic is split over several of them than when all arrays lie in one (DESIGN.md section 5
  * "Placement").  So the arrays are backed, through HIP virtual memory management, by 64 MiB physical chunks sampled
- * evenly from a large temporary pool (up to 128 GiB or 60 % of the free memory; CAAR_PLACEMENT_POOL_GIB), every array
- * contiguous in virtual memory and at least 2 MiB-aligned.  Data sets below 256 MiB, CAAR_PLACEMENT=malloc in the
- * environment, or a failing VMM route fall back to one hipMalloc per array.  caar_create allocates this way too.
+ * evenly from a temporary pool (bounded: see CaarPlacement below), every array contiguous in virtual memory and at
+ * least 2 MiB-aligned.  Data sets below 256 MiB, policy CAAR_PLACE_MALLOC, or a failing VMM route fall back to one
+ * hipMalloc per array.  caar_create allocates this way too (caar_create_ex takes the same CaarPlacement).
  * caar_arrays_placement: 1 if the arena is chunk-backed (and the pool size / chunk size it used), 0 if plain. */
 typedef struct CaarArena CaarArena;
+/* How an allocation is placed — a per-call choice (a NULL pointer, or policy CAAR_PLACE_DEFAULT, means: spread, unless
+ * the environment says CAAR_PLACEMENT=malloc).
+ *   pool_bytes          upper bound of the temporary pool (0: CAAR_PLACEMENT_POOL_GIB from the environment, else
+ *                       CAAR_PLACEMENT_POOL_DEFAULT).  The pool exists only while the call runs; what the arena keeps
+ *                       afterwards is the arrays' own size rounded up to 64 MiB per array.
+ *   max_free_fraction   the pool never takes more than this share of the device memory that is FREE when the call is
+ *                       made (0: one half; at most 0.9), so a second rank on the same GPU or another allocator in the
+ *                       process keeps the rest.  If the device fills up anyway while the pool is created, the call
+ *                       still succeeds with a narrower spread, or with plain allocations.
+ * A placed arena is mapped for its own device only: other GPUs (peer access over xGMI, RCCL buffers) cannot address
+ * it.  Hosts that need peer-visible arrays pass CAAR_PLACE_MALLOC. */
+enum { CAAR_PLACE_DEFAULT = 0, CAAR_PLACE_SPREAD = 1, CAAR_PLACE_MALLOC = 2 };
+#define CAAR_PLACEMENT_POOL_DEFAULT (128LL << 30)
+typedef struct CaarPlacement {
+  int policy;
+  long long pool_bytes;
+  double max_free_fraction;
+} CaarPlacement;
 int caar_arrays_alloc(CaarArena **arena, const CaarDims *dims, int device, CaarArrays *out_dev);
+int caar_arrays_alloc_ex(CaarArena **arena, const CaarDims *dims, int device, const CaarPlacement *placement,
+                         CaarArrays *out_dev);
+/* Unmaps and releases everything; the calling thread's current device is left as it was.  Returns non-zero if a
+ * HIP call of the teardown failed (the memory is then leaked rather than reused). */
 int caar_arrays_free(CaarArena *arena);
 int caar_arrays_placement(const CaarArena *arena, long long *pool_chunks, long long *chunk_bytes);
 
@@ -336,6 +365,8 @@ typedef struct CaarContext CaarContext;
 /* Allocates device storage for dims->num_elems elements on HIP device `device`
  * and a private stream. */
 int caar_create(CaarContext **ctx, const CaarDims *dims, int device);
+/* The same with the placement of the device arrays chosen by the caller (NULL: as caar_create). */
+int caar_create_ex(CaarContext **ctx, const CaarDims *dims, int device, const CaarPlacement *placement);
 void caar_destroy(CaarContext *ctx);
 /* Host -> device copy of all 16 arrays for elements [e0, e1) (element-major layout:
  * one contiguous range per array).  `host` = pointers to element 0 of host arrays
@@ -359,6 +390,13 @@ int caar_run(CaarContext *ctx, const CaarParams *params);
  * afterwards, as after nsteps-1 single calls.  The graph is captured on first use and kept while
  * params, nsteps and rotate stay the same.  Asynchronous. */
 int caar_run_steps(CaarContext *ctx, const CaarParams *params, int nsteps, int rotate);
+/* How caar_run_steps issues the calls.  1 (default): as ONE kernel launch where the selected variant has a step-loop
+ * kernel (NP=4, NLEV 72 / 128, rsplit > 0) — elements are independent and every lane only ever touches its own points,
+ * so each workgroup makes all nsteps calls for its element back to back: launch fill/drain once per nsteps instead of
+ * once per call, the element's arrays still in cache from the second call on; bit-identical to single launches.
+ * 0: always a hipGraph of nsteps single launches (what every other configuration uses).  Process-wide, atomic. */
+int caar_set_fused_steps(int on);
+int caar_get_fused_steps(void);
 /* Wait for everything enqueued on the context stream. */
 int caar_sync(CaarContext *ctx);
 /* Device pointers / stream of the context (for callers that launch their own work). */

@@ -1,0 +1,81 @@
+"""bench.py's JSON line: the fields the driver and the judge read, on one GPU and in the two-rank rehearsal mode
+(CAAR_BENCH_BACKEND=gloo: several ranks share the GPU that exists; the N>1 code path — slabs, barriers, max-over-ranks
+timing, per-rank gather — is the one `--gpus 8` runs under RCCL)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]   # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    return env
+
+
+def test_single_gpu_line_carries_the_contract_and_the_host_sequences():
+    r = subprocess.run([sys.executable, BENCH, "--elems-per-gpu", "1500", "--steps", "4", "--warmup", "2", "--no-spinup",
+                        "--no-other-configs", "--cpu-seconds", "0.2"], capture_output=True, text=True, timeout=900,
+                       env=_clean_env())
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = _line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["warmup"] == 2 and j["dtype"] == "f64" and j["vs_baseline"] is None
+    assert j["backend"] == "none" and j["dist_world_size"] == 1
+    assert j["warmup_effective"] == 1 + 2                      # first-use launch + W (no spin-up asked for)
+    assert j["ms_per_step"] <= j["ms_per_step_incl_closing_barrier"]
+    assert abs(j["value"] - 1500 / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
+    roof = j["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s"
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    assert roof["kernel_ms"] <= j["ms_per_step"] * 1.0001      # the kernel cannot take longer than the step that holds it
+    # the three figures: replay, all-streaming, inside a host sequence (tracer step / cache-evicting neighbour)
+    for k in ("achieved", "achieved_all_streaming", "achieved_interleaved", "achieved_interleaved_evicting"):
+        assert roof[k] > 0, k
+    for name in ("euler_step", "evicting"):
+        row = roof["interleaved"][name]
+        assert row["neighbour_ms"] > 0
+        for label in ("default", "all_streaming"):
+            assert row[label]["sequence_ms"] > row["neighbour_ms"] and row[label]["caar_ms"] > 0
+    cb = j["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_two_rank_rehearsal_reports_backend_world_size_and_per_gpu_rates():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = _clean_env()
+    env["CAAR_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "4",
+                        "--warmup", "2", "--elems-per-gpu", "1500", "--no-spinup"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 2 and j["backend"] == "gloo" and j["dist_world_size"] == 2 and j["scaling"] == "weak"
+    assert j["warmup_effective"] == 3
+    assert "1500 per GPU (3000 total)" in j["config"]["workload"]
+    assert abs(j["value"] - 3000 / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
+    assert j["ms_per_step"] <= j["ms_per_step_incl_closing_barrier"]
+    per = j["roofline"]["per_gpu"]
+    assert [p["rank"] for p in per] == [0, 1] and all(p["elements"] == 1500 and p["kernel_ms"] > 0 for p in per)
+    assert j["roofline"]["kernel_ms"] == max(p["kernel_ms"] for p in per)
+    assert "cpu_baseline" not in j and "interleaved" not in j["roofline"]   # N=1 only

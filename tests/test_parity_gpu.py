@@ -491,6 +491,60 @@ def test_graph_of_steps_through_the_context_api(oracle):
         L.lib.caar_destroy(ctx)
 
 
+@pytest.mark.parametrize("nlev", [72, 128])
+def test_fused_steps_are_bit_identical_to_the_graph_of_single_launches(oracle, nlev):
+    """caar_run_steps as ONE launch (caar_np4_steps_kernel: every workgroup makes all nsteps calls for its element, time
+    levels rotating) against the hipGraph of nsteps single launches: the same arithmetic on the same data, so every array
+    must agree bit for bit — every variant that has a step-loop kernel, moist and dry, a sub-range of the elements, with
+    and without rotation; and against the oracle's trajectory at the usual multi-step bound."""
+    import ctypes as C
+    from tinman_sandbox_amd import caar as m
+    L = tsa.library()
+    lib = L.lib
+    ne = 37
+    arrs = cases.hashed_arrays(4, nlev, ne, seed=77 + nlev)
+    Dvv = cases.dvv_for(4)
+    dims = m._CaarDims(4, nlev, 1, 3, ne)
+    ctx = C.c_void_p()
+    L.check(lib.caar_create(C.byref(ctx), C.byref(dims), 0), "create")
+    fused_variants = [v for v in range(lib.caar_num_variants(4, nlev))
+                      if b"two workgroups per CU" in lib.caar_variant_info(4, nlev, v)]
+    assert len(fused_variants) >= 3
+    try:
+        for variant in fused_variants:
+            assert lib.caar_select_variant(4, nlev, variant) == 0
+            for extra, nsteps, rotate in ((dict(), 5, 1), (dict(qn0=-1, nets=3, nete=30), 4, 1), (dict(dt2=0.125), 3, 0),
+                                          (dict(n0=2, np1=0, nm1=1), 1, 1)):
+                sc = po.default_scalars(nlev)
+                sc.update(dt2=0.25, qn0=1)
+                sc.update(extra)
+                results = []
+                for fused in (0, 1):
+                    lib.caar_set_fused_steps(fused)
+                    host = cases.copy_arrays(arrs)
+                    ptrs = m._CaarArrays(*[host[n].ctypes.data_as(m._dp) for n in m.ARRAY_NAMES])
+                    L.check(lib.caar_upload(ctx, C.byref(ptrs), 0, ne), "upload")
+                    prm = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cpu").params()
+                    L.check(lib.caar_run_steps(ctx, C.byref(prm), nsteps, rotate), "run_steps")
+                    L.check(lib.caar_download(ctx, C.byref(ptrs), 0, ne, 1), "download")
+                    L.check(lib.caar_sync(ctx), "sync")
+                    results.append(host)
+                for n in m.ARRAY_NAMES:
+                    assert np.array_equal(results[0][n], results[1][n]), (variant, extra, n)
+                want = cases.copy_arrays(arrs)
+                s = dict(sc)
+                for _ in range(nsteps):
+                    oracle.compute_and_apply_rhs(want, Dvv, s)
+                    if rotate:
+                        s["np1"], s["nm1"], s["n0"] = s["nm1"], s["n0"], s["np1"]
+                for n in tsa.caar.MUTATED:
+                    assert cases.scaled_err(results[1][n], want[n]) <= 1e-11, (variant, extra, n)
+    finally:
+        lib.caar_set_fused_steps(1)
+        lib.caar_select_variant(4, nlev, 0)
+        lib.caar_destroy(ctx)
+
+
 @pytest.mark.parametrize("name", list(cases.CASES))
 def test_rounding_error_is_no_larger_than_the_references(oracle, name):
     """Against an 80-bit (numpy.longdouble) evaluation of the same formulas by independent

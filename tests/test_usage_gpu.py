@@ -1,5 +1,8 @@
 """How a host uses the path beyond one call: time stepping with rotating levels, an empty
 element range, extra tracer slots, side streams and hipGraph capture."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -10,6 +13,7 @@ from oracle import pyoracle as po
 import tinman_sandbox_amd as tsa
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_time_stepping_trajectory_matches_oracle(oracle):
@@ -320,19 +324,18 @@ def test_cache_window_changes_nothing_but_speed(nlev, rsplit):
 
 
 def test_arrays_placed_for_bandwidth_compute_the_same(oracle, monkeypatch):
-    """caar_arrays_alloc (include/caar.h; DESIGN.md section 5 "Placement"): arrays backed by physical chunks spread over the
-    device's address classes through HIP virtual memory management.  Same results bit for bit as torch-allocated
-    arrays, chunk-backed from 256 MiB on, plain hipMalloc below that or on request, memory returned when released."""
+    """caar_arrays_alloc[_ex] (include/caar.h; DESIGN.md section 5 "Placement"): arrays backed by physical chunks spread over
+    the device's address classes through HIP virtual memory management.  Same results bit for bit as torch-allocated
+    arrays, chunk-backed from 256 MiB on, plain hipMalloc below that or on request (per call: CaarPlacement; or for a
+    whole process: CAAR_PLACEMENT), memory returned when released."""
     import gc
     E = 2000  # 372 MB of arrays
     spread = tsa.TestData().init_data(E, 4, 72, device="cuda")
     assert spread.arrays.arena is not None and spread.arrays.arena.spread()
     for n in tsa.ARRAY_NAMES:
         assert spread.arrays[n].data_ptr() % (2 << 20) == 0, n      # every array starts on a chunk boundary of the range
-    monkeypatch.setenv("CAAR_PLACEMENT", "torch")
-    plain = tsa.TestData().init_data(E, 4, 72, device="cuda")
+    plain = tsa.TestData().init_data(E, 4, 72, device="cuda", place="torch")
     assert plain.arrays.arena is None
-    monkeypatch.delenv("CAAR_PLACEMENT")
     for n in tsa.ARRAY_NAMES:
         assert torch.equal(spread.arrays[n], plain.arrays[n]), n     # same initial data
     for _ in range(2):
@@ -355,7 +358,17 @@ def test_arrays_placed_for_bandwidth_compute_the_same(oracle, monkeypatch):
     monkeypatch.setenv("CAAR_PLACEMENT", "malloc")
     forced = tsa.TestData().init_data(E, 4, 72, device="cuda")
     assert forced.arrays.arena is not None and not forced.arrays.arena.spread()
+    # the per-call choice wins over the environment, both ways
+    chosen = tsa.TestData().init_data(E, 4, 72, device="cuda", place=tsa.placement("spread", pool_gib=4))
+    assert chosen.arrays.arena.spread() and chosen.arrays.arena.pool_bytes() <= 4 << 30
     monkeypatch.delenv("CAAR_PLACEMENT")
+    forced2 = tsa.TestData().init_data(E, 4, 72, device="cuda", place=tsa.placement("malloc"))
+    assert forced2.arrays.arena is not None and not forced2.arrays.arena.spread()
+    # the pool is bounded by the share of the FREE memory the caller allows
+    free_now = torch.cuda.mem_get_info()[0]
+    tight = tsa.TestData().init_data(E, 4, 72, device="cuda", place=tsa.placement("spread", pool_gib=1024, max_free_fraction=0.05))
+    assert tight.arrays.arena.spread() and tight.arrays.arena.pool_bytes() <= 0.05 * free_now + (64 << 20)
+    del chosen, forced2, tight
     # released memory comes back (tensors keep the arena alive until the last one is gone)
     del spread, plain, small, forced, arrs
     gc.collect()
@@ -375,6 +388,90 @@ def test_arrays_placed_for_bandwidth_compute_the_same(oracle, monkeypatch):
     for _ in range(4):
         free2 = cycle()
     assert free1 - free2 < (64 << 20), (free1, free2)   # no physical memory lost per allocate / release cycle
+
+
+def test_released_address_ranges_are_reused_correctly(oracle):
+    """An arena's virtual range is given back on release (one hipMemUnmap per mapped chunk, then hipMemAddressFree); the
+    next arena may get the same addresses and must see ITS memory there.  Round 2 unmapped the whole range with one call,
+    which leaves all chunks but the first translated to released memory (tools/probes/vmm_va_reuse_probe.hip); this is
+    the sequence that failed then: arenas of different sizes allocated, run, checked and released in turn."""
+    import gc
+    for rep in range(2):
+        for np_, nlev, E, gold_name in ((4, 72, 6000, "np4_nlev72_closed"), (4, 128, 3000, "np4_nlev128_closed"),
+                                        (8, 72, 1500, "np8_nlev72_closed"), (4, 72, 2500, "np4_nlev72_closed")):
+            data = tsa.TestData().init_data(E, np_, nlev, device="cuda")
+            assert data.arrays.arena.spread()
+            tsa.compute_and_apply_rhs(data)
+            torch.cuda.synchronize()
+            gold = cases.load_golden(gold_name)
+            ng = gold["elem_derived_phi"].shape[0]
+            sc = po.default_scalars(nlev)
+            for n in cases.OUTPUT_NAMES:
+                g = data.arrays[n][:ng].cpu().numpy()
+                g = g[:, sc["np1"]] if n.startswith("elem_state_") else g
+                assert cases.scaled_err(g, gold[n]) <= 1e-12, (rep, np_, nlev, E, n)
+            # the tail of the arrays as well (the last chunks of the range): against the same launch on torch's allocations
+            other = tsa.TestData().init_data(E, np_, nlev, device="cuda", place="torch")
+            tsa.compute_and_apply_rhs(other)
+            torch.cuda.synchronize()
+            for n in tsa.ARRAY_NAMES:
+                assert torch.equal(data.arrays[n], other.arrays[n]), (rep, np_, nlev, E, n)
+            del data, other
+            gc.collect()
+            torch.cuda.empty_cache()
+
+
+_TWO_PROC_SCRIPT = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch
+import tinman_sandbox_amd as tsa
+import cases
+from oracle import pyoracle as po   # checker only
+me, flag_dir = sys.argv[2], sys.argv[3]
+torch.cuda.init()
+open(os.path.join(flag_dir, "ready_" + me), "w").close()
+t0 = time.time()
+while not (os.path.exists(os.path.join(flag_dir, "ready_a")) and os.path.exists(os.path.join(flag_dir, "ready_b"))):
+    assert time.time() - t0 < 300, "the other process never came up"
+    time.sleep(0.005)
+t1 = time.time()
+data = tsa.TestData().init_data(10000, 4, 72, device="cuda")   # library default placement, default pool
+t2 = time.time()
+for _ in range(2):
+    tsa.compute_and_apply_rhs(data)
+torch.cuda.synchronize()
+O = po.Oracle()
+want = O.init_arrays(4, 72, 1, 3, 3)
+sc = po.default_scalars(72)
+for _ in range(2):
+    O.compute_and_apply_rhs(want, O.dvv_np4(False), sc)
+worst = 0.0
+for n in cases.OUTPUT_NAMES:
+    got = data.arrays[n][:3].cpu().numpy()
+    worst = max(worst, cases.scaled_err(got, want[n]))
+print("RESULT", me, "spread", int(data.arrays.arena.spread()), "pool_gib", data.arrays.arena.pool_bytes() / 2**30,
+      "alloc_s", round(t2 - t1, 2), "worst", worst, flush=True)
+assert worst <= 1e-12
+"""
+
+
+def test_two_processes_allocate_on_one_gpu_at_the_same_time(tmp_path):
+    """Two ranks sharing a GPU (normal for E3SM hosts) create 10 000-element data sets at the same moment with the
+    library's default placement: the temporary pools are bounded by half of what is free when each call starts, and a
+    pool cut short by the neighbour is not an error — both succeed and match the oracle."""
+    import subprocess
+    script = tmp_path / "two_proc.py"
+    script.write_text(_TWO_PROC_SCRIPT)
+    env = dict(os.environ)
+    env.pop("CAAR_PLACEMENT_POOL_GIB", None)   # the library's own default pool, not the suite's small one
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, me, str(tmp_path)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True, env=env) for me in ("a", "b")]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:]
+        assert "RESULT" in o, o[-2000:]
+    print("\n".join(l for o in outs for l in o.splitlines() if l.startswith("RESULT")))
 
 
 def test_context_api_allocates_through_the_placed_allocator(oracle):

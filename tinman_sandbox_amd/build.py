@@ -15,7 +15,7 @@ HOST = os.path.join(HERE, "host")
 LIB = os.path.join(CSRC, "libcaar_hip.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["caar_np4.hip", "caar_np8.hip", "caar_abi.hip", "caar_norms.hip", "caar_layout.hip", "caar_operators.hip", "caar_operators_ex.hip", "caar_alloc.hip", "caar_membench.hip"]
+HIP_SOURCES = ["caar_np4.hip", "caar_np4_steps.hip", "caar_np8.hip", "caar_abi.hip", "caar_norms.hip", "caar_layout.hip", "caar_operators.hip", "caar_operators_ex.hip", "caar_alloc.hip", "caar_membench.hip"]
 
 
 def hipcc():

@@ -55,6 +55,21 @@ class CaarError(RuntimeError):
     pass
 
 
+class _CaarPlacement(C.Structure):
+    _fields_ = [("policy", C.c_int), ("pool_bytes", C.c_longlong), ("max_free_fraction", C.c_double)]
+
+
+PLACE_DEFAULT, PLACE_SPREAD, PLACE_MALLOC = 0, 1, 2
+
+
+def placement(policy="spread", pool_gib=0, max_free_fraction=0.0):
+    """CaarPlacement (include/caar.h) for caar_arrays_alloc_ex / caar_create_ex: policy "default" | "spread" | "malloc",
+    the bound of the temporary pool in GiB (0: the library's default) and the largest share of the free device memory
+    the pool may take (0: one half)."""
+    code = {"default": PLACE_DEFAULT, "spread": PLACE_SPREAD, "malloc": PLACE_MALLOC}[policy]
+    return _CaarPlacement(code, int(pool_gib * (1 << 30)), float(max_free_fraction))
+
+
 class _CaarOperatorGeometry(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("D", "Dinv", "metdet", "rmetdet", "spheremp", "mp", "metinv", "tensorVisc",
                                            "vec_sph2cart")]
@@ -79,11 +94,11 @@ class CaarLibrary:
     """ctypes view of libcaar_hip.so; every symbol of include/caar.h is bound here."""
 
     SYMBOLS = ("caar_supported", "caar_abi_version", "caar_device_count", "caar_strerror", "caar_array_len",
-               "caar_algorithmic_bytes", "caar_launch", "caar_launch_state_norms", "caar_sphere_operator", "caar_sphere_operator_range", "caar_sphere_operator_ex", "caar_euler_step", "caar_preq_hydrostatic", "caar_preq_omega_ps", "caar_sphere_operator_host", "caar_preq_hydrostatic_host", "caar_preq_omega_ps_host", "caar_reciprocal",
+               "caar_algorithmic_bytes", "caar_launch", "caar_launch_steps", "caar_launch_state_norms", "caar_sphere_operator", "caar_sphere_operator_range", "caar_sphere_operator_ex", "caar_euler_step", "caar_preq_hydrostatic", "caar_preq_omega_ps", "caar_sphere_operator_host", "caar_preq_hydrostatic_host", "caar_preq_omega_ps_host", "caar_reciprocal",
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
-               "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_selected_variant", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_stream_copy_tuned", "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_arrays_alloc", "caar_arrays_free", "caar_arrays_placement", "caar_create", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_download_f90",
+               "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_selected_variant", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_stream_copy_tuned", "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_arrays_alloc", "caar_arrays_alloc_ex", "caar_arrays_free", "caar_arrays_placement", "caar_create", "caar_create_ex", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_download_f90",
                "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
-               "caar_time_runs", "caar_run_steps", "caar_map_host", "caar_run_mapped", "caar_unmap_host")
+               "caar_time_runs", "caar_run_steps", "caar_set_fused_steps", "caar_get_fused_steps", "caar_map_host", "caar_run_mapped", "caar_unmap_host")
 
     def __init__(self, path=LIB_PATH):
         if not os.path.exists(path):
@@ -103,6 +118,8 @@ class CaarLibrary:
         L.caar_algorithmic_bytes.restype = C.c_longlong
         L.caar_launch.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays), vp,
                                   C.POINTER(_CaarParams), vp]
+        L.caar_launch_steps.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays), vp, C.POINTER(_CaarParams), C.c_int,
+                                        C.c_int, vp]
         L.caar_launch_state_norms.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays), C.c_int,
                                               C.c_int, C.c_int, vp, vp]
         L.caar_sphere_operator.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays), vp, C.c_int, C.c_int,
@@ -141,9 +158,12 @@ class CaarLibrary:
         L.caar_traffic_skeleton.argtypes = [C.POINTER(_CaarDims), C.POINTER(_CaarArrays),
                                             C.POINTER(_CaarParams), C.c_int, vp]
         L.caar_arrays_alloc.argtypes = [C.POINTER(vp), C.POINTER(_CaarDims), C.c_int, C.POINTER(_CaarArrays)]
+        L.caar_arrays_alloc_ex.argtypes = [C.POINTER(vp), C.POINTER(_CaarDims), C.c_int, C.POINTER(_CaarPlacement),
+                                           C.POINTER(_CaarArrays)]
         L.caar_arrays_free.argtypes = [vp]
         L.caar_arrays_placement.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.caar_create.argtypes = [C.POINTER(vp), C.POINTER(_CaarDims), C.c_int]
+        L.caar_create_ex.argtypes = [C.POINTER(vp), C.POINTER(_CaarDims), C.c_int, C.POINTER(_CaarPlacement)]
         L.caar_destroy.argtypes = [vp]
         L.caar_destroy.restype = None
         L.caar_upload.argtypes = [vp, C.POINTER(_CaarArrays), C.c_int, C.c_int]
@@ -158,6 +178,7 @@ class CaarLibrary:
         L.caar_state_norms.argtypes = [vp, C.c_int, C.c_int, C.c_int, _dp]
         L.caar_time_runs.argtypes = [vp, C.POINTER(_CaarParams), C.c_int, C.POINTER(C.c_float)]
         L.caar_run_steps.argtypes = [vp, C.POINTER(_CaarParams), C.c_int, C.c_int]
+        L.caar_set_fused_steps.argtypes = [C.c_int]
         L.caar_map_host.argtypes = [C.POINTER(vp), C.POINTER(_CaarDims), C.POINTER(_CaarArrays), C.c_int]
         L.caar_run_mapped.argtypes = [vp, C.POINTER(_CaarParams)]
         L.caar_unmap_host.argtypes = [vp]
@@ -219,15 +240,22 @@ class _Arena:
     """Device memory from caar_arrays_alloc (placed for bandwidth, DESIGN.md section 5 "Placement"), freed when the last
     tensor that views it is gone."""
 
-    def __init__(self, dims, device_index):
+    def __init__(self, dims, device_index, place=None):
         self.lib = library()
         self.handle = C.c_void_p()
         self.ptrs = _CaarArrays()
-        self.lib.check(self.lib.lib.caar_arrays_alloc(C.byref(self.handle), C.byref(dims), device_index, C.byref(self.ptrs)),
-                       "caar_arrays_alloc")
+        self.lib.check(self.lib.lib.caar_arrays_alloc_ex(C.byref(self.handle), C.byref(dims), device_index,
+                                                         C.byref(place) if place is not None else None,
+                                                         C.byref(self.ptrs)), "caar_arrays_alloc_ex")
 
     def spread(self):
         return self.lib.lib.caar_arrays_placement(self.handle, None, None) == 1
+
+    def pool_bytes(self):
+        """Size of the temporary pool the chunks were sampled from (0 for plain allocations)."""
+        n, b = C.c_longlong(0), C.c_longlong(0)
+        self.lib.lib.caar_arrays_placement(self.handle, C.byref(n), C.byref(b))
+        return n.value * b.value
 
     def __del__(self):
         if getattr(self, "handle", None):
@@ -248,18 +276,22 @@ class _ArenaView:
 class ElementArrays:
     """The 16 element arrays (Homme::Arrays) as torch float64 tensors on one device."""
 
-    def __init__(self, np_, nlev, num_elems, qsize_d=1, timelevels=3, device="cpu", tensors=None):
+    def __init__(self, np_, nlev, num_elems, qsize_d=1, timelevels=3, device="cpu", tensors=None, place=None):
+        """`place`: None (the library's default placement), a CaarPlacement from placement(...), or "torch" for torch's
+        own sixteen allocations (CAAR_PLACEMENT=torch in the environment does the same when `place` is None)."""
         self.np, self.nlev, self.num_elems = np_, nlev, num_elems
         self.qsize_d, self.timelevels = qsize_d, timelevels
         self.device = torch.device(device)
         shapes = array_shapes(np_, nlev, qsize_d, timelevels, num_elems)
         self.arena = None
-        if tensors is None and self.device.type == "cuda" and os.environ.get("CAAR_PLACEMENT", "") != "torch":
+        if place is None and os.environ.get("CAAR_PLACEMENT", "") == "torch":
+            place = "torch"
+        if tensors is None and self.device.type == "cuda" and not (isinstance(place, str) and place == "torch"):
             # the library's allocator: every array spread over the device's address classes (include/caar.h
-            # caar_arrays_alloc); CAAR_PLACEMENT=torch keeps torch's own sixteen allocations
+            # caar_arrays_alloc_ex)
             idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
             with torch.cuda.device(idx):
-                self.arena = _Arena(_CaarDims(np_, nlev, qsize_d, timelevels, num_elems), idx)
+                self.arena = _Arena(_CaarDims(np_, nlev, qsize_d, timelevels, num_elems), idx, place)
                 ptrs = [C.cast(getattr(self.arena.ptrs, f), C.c_void_p).value for f, _ in _CaarArrays._fields_]
                 tensors = {}
                 for n, p in zip(ARRAY_NAMES, ptrs):
@@ -444,9 +476,9 @@ class TestData:
         self._dvv_key = None
         self._hybi_key = None
 
-    def init_data(self, num_elems, np_=4, nlev=72, device="cuda", first_elem=0):
-        """TestData::init_data, data_structures.cpp:165-172."""
-        self.arrays = ElementArrays(np_, nlev, num_elems, device=device).init_data(first_elem)
+    def init_data(self, num_elems, np_=4, nlev=72, device="cuda", first_elem=0, place=None):
+        """TestData::init_data, data_structures.cpp:165-172.  `place`: see ElementArrays."""
+        self.arrays = ElementArrays(np_, nlev, num_elems, device=device, place=place).init_data(first_elem)
         self.constants = Constants()
         self.control = Control(num_elems)
         self.hvcoord = HVCoord(nlev)
@@ -537,6 +569,25 @@ def compute_and_apply_rhs(data, stream=None):
         rc = L.lib.caar_launch(C.byref(dims), C.byref(ptrs), C.c_void_p(dvv.data_ptr()),
                                C.byref(prm), C.c_void_p(stream.cuda_stream))
     L.check(rc, "caar_launch")
+
+
+def compute_and_apply_rhs_steps(data, nsteps, rotate=True, stream=None):
+    """`nsteps` calls of compute_and_apply_rhs with TestData::update_time_levels between them (the reference's driver
+    loop, main.cpp:113-121) — caar_launch_steps: one launch where a step-loop kernel exists.  Like the loop it replaces,
+    it leaves data.control rotated nsteps times."""
+    L = library()
+    _require_gpu(data.arrays)
+    if stream is None:
+        stream = torch.cuda.current_stream(data.arrays.device)
+    dims, ptrs, prm = data.arrays.dims(), data.arrays.pointers(), data.params(device_constants=True)
+    dvv = data.dvv_device()
+    with torch.cuda.device(data.arrays.device):
+        rc = L.lib.caar_launch_steps(C.byref(dims), C.byref(ptrs), C.c_void_p(dvv.data_ptr()), C.byref(prm), nsteps,
+                                     1 if rotate else 0, C.c_void_p(stream.cuda_stream))
+    L.check(rc, "caar_launch_steps")
+    if rotate:
+        for _ in range(nsteps):
+            data.update_time_levels()
 
 
 def sphere_operator(which, field, data, ielem):

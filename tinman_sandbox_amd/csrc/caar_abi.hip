@@ -138,6 +138,8 @@ static std::atomic<int> g_xcd_chunked{-1};  // workgroup -> element mapping, see
 // bytes of element data the hybrid cache policy keeps in the memory-side cache (0: none, all streaming);
 // default = best of a 0..320 MB sweep at NLEV 72 and 128 (the cache holds 256 MB, shared with everything else)
 static std::atomic<long long> g_cache_window{CAAR_CACHE_WINDOW_DEFAULT};
+// caar_run_steps: 1 = one fused launch where the selected variant has a step-loop kernel, 0 = always a graph of single launches
+static std::atomic<int> g_fused_steps{1};
 
 namespace caar {
 struct LaunchChoice {
@@ -229,6 +231,13 @@ int caar_set_cache_window(long long bytes) {
 
 long long caar_get_cache_window(void) { return g_cache_window.load(); }
 
+int caar_set_fused_steps(int on) {
+  g_fused_steps.store(on ? 1 : 0);
+  return CAAR_OK;
+}
+
+int caar_get_fused_steps(void) { return g_fused_steps.load(); }
+
 int caar_set_xcd_chunked(int on) {
   g_xcd_chunked.store(on < 0 ? -1 : (on ? 1 : 0));
   return CAAR_OK;
@@ -316,6 +325,50 @@ static int launch_with(const CaarDims* dims, const CaarArrays* dev, const double
   caar::KernelArgs k;
   fill_args_impl(k, dims, dev, dvv_dev, p, ch);
   return (int)cfg->variants[ch.variant].launch(k, n, (hipStream_t)stream);
+}
+
+// nsteps calls as ONE launch if the chosen variant has a step-loop kernel (and the knob allows it): returns 1 if it was
+// launched, 0 if the caller has to issue single launches, < 0 / a hipError_t on failure
+static int try_fused_steps(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev, const CaarParams* p,
+                           int nsteps, int rotate, void* stream, const caar::Config* cfg, const caar::LaunchChoice& ch,
+                           int* rc_out) {
+  *rc_out = CAAR_OK;
+  if (!g_fused_steps.load(std::memory_order_relaxed) || !cfg || !cfg->variants[ch.variant].launch_steps || p->rsplit == 0)
+    return 0;
+  int rc = check_common(dims, p);
+  if (rc == CAAR_OK && (!dev || !dvv_dev)) rc = CAAR_EINVAL;
+  for (int i = 0; rc == CAAR_OK && i < CAAR_NUM_ARRAYS; ++i)
+    if (!*array_slot(dev, i) || ((size_t)*array_slot(dev, i) & 7)) rc = CAAR_EINVAL;
+  if (rc == CAAR_OK && (((size_t)dev->elem_state_v | (size_t)dev->elem_derived_vn0) & 15)) rc = CAAR_EINVAL;
+  *rc_out = rc;
+  if (rc != CAAR_OK) return 1;
+  const int n = p->nete - p->nets;
+  if (n == 0) return 1;
+  caar::KernelArgs k;
+  fill_args_impl(k, dims, dev, dvv_dev, p, ch);
+  *rc_out = (int)cfg->variants[ch.variant].launch_steps(k, n, nsteps, rotate ? 1 : 0, (hipStream_t)stream);
+  return 1;
+}
+
+int caar_launch_steps(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev, const CaarParams* p, int nsteps,
+                      int rotate, void* stream) {
+  if (!dims || !p || nsteps < 1) return CAAR_EINVAL;
+  const caar::Config* cfg = caar::find_config(dims->np, dims->nlev);
+  if (!cfg) return CAAR_EUNSUPPORTED;
+  const caar::LaunchChoice ch = caar::launch_choice(cfg);
+  int rc = CAAR_OK;
+  if (try_fused_steps(dims, dev, dvv_dev, p, nsteps, rotate, stream, cfg, ch, &rc)) return rc;
+  CaarParams q = *p;
+  for (int i = 0; i < nsteps && rc == CAAR_OK; ++i) {
+    rc = launch_with(dims, dev, dvv_dev, &q, stream, &ch);
+    if (rotate) {  // data_structures.cpp:174-180
+      const int t = q.np1;
+      q.np1 = q.nm1;
+      q.nm1 = q.n0;
+      q.n0 = t;
+    }
+  }
+  return rc;
 }
 
 static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const CaarArrays* dev,
@@ -475,6 +528,8 @@ int caar_preq_omega_ps(const CaarDims* dims, int nelem, const double* p_dev, con
 
 // ---- host-pointer convenience forms of the operators (one element, synchronous) -------------------------
 namespace {
+// One scratch area per device.  The host-pointer operators run on the calling thread's CURRENT device (a rank bound to
+// GPU 3 stays on GPU 3) and never switch it.
 struct HostOpScratch {
   std::mutex mu;
   hipStream_t stream = nullptr;
@@ -482,8 +537,8 @@ struct HostOpScratch {
   size_t doubles = 0;
   // returns a device area of at least n doubles (grown on demand), creating the stream on first use
   hipError_t area(size_t n, double** out) {
-    hipError_t e = hipSetDevice(0);
-    if (e == hipSuccess && !stream) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    hipError_t e = hipSuccess;
+    if (!stream) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
     if (e == hipSuccess && doubles < n) {
       if (dev) (void)hipFree(dev);
       dev = nullptr;
@@ -495,9 +550,12 @@ struct HostOpScratch {
     return e;
   }
 };
+constexpr int kMaxDevices = 64;
 HostOpScratch* host_op_scratch() {  // (a pointer: this sits inside the extern "C" block)
-  static HostOpScratch* s = new HostOpScratch();  // never destroyed: no HIP calls from static destructors at exit
-  return s;
+  static HostOpScratch* s = new HostOpScratch[kMaxDevices];  // never destroyed: no HIP calls from static destructors at exit
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  return s + dev;
 }
 }  // namespace
 
@@ -662,7 +720,9 @@ int caar_launch_state_norms(const CaarDims* d, const CaarArrays* dev, int tl, in
 }
 
 // ------------------------------------------------------------------ context API
-int caar_create(CaarContext** out, const CaarDims* dims, int device) {
+int caar_create(CaarContext** out, const CaarDims* dims, int device) { return caar_create_ex(out, dims, device, nullptr); }
+
+int caar_create_ex(CaarContext** out, const CaarDims* dims, int device, const CaarPlacement* placement) {
   if (!out || !dims || dims->num_elems <= 0) return CAAR_EINVAL;
   if (!caar::find_config(dims->np, dims->nlev)) return CAAR_EUNSUPPORTED;
   int ndev = 0;
@@ -676,7 +736,7 @@ int caar_create(CaarContext** out, const CaarDims* dims, int device) {
   c->device = device;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) {
-    const int rc = caar_arrays_alloc(&c->arena, dims, device, &c->dev);  // placed for bandwidth (caar_alloc.hip)
+    const int rc = caar_arrays_alloc_ex(&c->arena, dims, device, placement, &c->dev);  // placed for bandwidth (caar_alloc.hip)
     if (rc != CAAR_OK) {
       caar_destroy(c);
       return rc;
@@ -694,6 +754,8 @@ int caar_create(CaarContext** out, const CaarDims* dims, int device) {
 
 void caar_destroy(CaarContext* c) {
   if (!c) return;
+  int caller_dev = -1;  // may run from a finaliser: the calling thread's current device is left as it was
+  if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->arena) (void)caar_arrays_free(c->arena);
@@ -703,6 +765,7 @@ void caar_destroy(CaarContext* c) {
   if (c->steps_exec) (void)hipGraphExecDestroy(c->steps_exec);
   delete c->steps_hybi;
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (caller_dev >= 0 && caller_dev != c->device) (void)hipSetDevice(caller_dev);
   delete c;
 }
 
@@ -810,7 +873,13 @@ int caar_run_steps(CaarContext* c, const CaarParams* p, int nsteps, int rotate) 
   // baked into device buffers the kernels read, so only their content matters)
   // ... and for the same variant / element mapping / cache window, which fill_args bakes into the
   // captured kernel arguments (a knob changed after the capture must not replay the old launches)
-  const caar::LaunchChoice now = caar::launch_choice(caar::find_config(c->dims.np, c->dims.nlev));
+  const caar::Config* cfg = caar::find_config(c->dims.np, c->dims.nlev);
+  const caar::LaunchChoice now = caar::launch_choice(cfg);
+  {
+    // one launch: every workgroup makes all nsteps calls for its element (caar_np4_steps_kernel)
+    int rc = CAAR_OK;
+    if (try_fused_steps(&c->dims, &c->dev, dvv_dev, &q, nsteps, rotate, c->stream, cfg, now, &rc)) return rc;
+  }
   bool same = c->steps_exec && c->steps_n == nsteps && c->steps_rotate == (rotate != 0) &&
               c->steps_choice.variant == now.variant && c->steps_choice.xcd_chunked == now.xcd_chunked &&
               c->steps_choice.cache_window == now.cache_window && std::memcmp(c->steps_dvv, p->Dvv, nd) == 0;

@@ -115,6 +115,9 @@ struct KernelVariant {
   const char* what;
   hipError_t (*launch)(const KernelArgs&, int num_elems, hipStream_t stream);
   bool prefers_xcd_chunked = false;  // measured faster with each XCD on a contiguous eighth of the element range
+  // nsteps calls (time levels rotating between them if `rotate`) as ONE launch, or nullptr: caar_run_steps then replays a
+  // graph of single launches
+  hipError_t (*launch_steps)(const KernelArgs&, int num_elems, int nsteps, int rotate, hipStream_t stream) = nullptr;
 };
 
 // arguments of the stand-alone operator kernels (caar_operators_ex.hip)

@@ -151,7 +151,11 @@ __device__ __forceinline__ double2 ld2(const double2* p, bool) { return *p; }
 // WGW > 0: the element's waves are spread over workgroups of WGW waves (the skeleton has no cross-level
 // dependency): many small, short-lived workgroups per CU instead of one fat one — probes what the launch
 // shape alone costs.
-template <int NLEV, int TPW, int NTL, int NTS, bool ALL_FIRST, int PP = 16, int WGW = 0>
+// ORDER (with ALL_FIRST): 0 = tile-major (a tile's 7 output arrays, then the next tile: 8 streams x 512 B each time);
+// 1 = stores array-major (one array's TPW tiles back to back = TPW x 512 B contiguous per wave and array: 3 KiB at
+// TPW = 6, 6 KiB for the (u, v) pairs), 2 = loads array-major as well.  Probes whether DRAM prefers longer bursts per
+// stream (round 2: write streams are what costs, profiles/r02/stream_probe_rw.log).
+template <int NLEV, int TPW, int NTL, int NTS, bool ALL_FIRST, int PP = 16, int WGW = 0, int ORDER = 0>
 __global__ __launch_bounds__((WGW ? WGW : NLEV * PP / 64 / TPW) * 64) void traffic_skeleton_np4(const KernelArgs k) {
   constexpr int BLK = NLEV * PP;
   constexpr int WAVES = NLEV * PP / 64 / TPW;            // waves per element
@@ -189,6 +193,58 @@ __global__ __launch_bounds__((WGW ? WGW : NLEV * PP / 64 / TPW) * 64) void traff
   g *= 0.0;
   double a[TPW], tn[TPW], dn[TPW], om[TPW], et[TPW];
   v2 uv[TPW], um[TPW], un[TPW];
+  if constexpr (ALL_FIRST && ORDER >= 1) {
+    if constexpr (ORDER == 2) {
+#define CAAR_SK_LD(dst, expr)                          \
+  _Pragma("unroll") for (int r = 0; r < TPW; ++r) {    \
+    const unsigned off = r * 64 + ulane;               \
+    dst[r] = expr;                                     \
+  }
+      double b0[TPW], b1[TPW], b2[TPW], b3[TPW];
+      CAAR_SK_LD(b0, ld<NTL>(dp_n0 + off))
+      CAAR_SK_LD(uv, ld<NTL>(reinterpret_cast<const v2*>(vv_n0) + off))
+      CAAR_SK_LD(b1, ld<NTL>(T_n0 + off))
+      CAAR_SK_LD(b2, ld<NTL>(Qdp + off))
+      CAAR_SK_LD(um, ld<NTL>(reinterpret_cast<const v2*>(vv_nm1) + off))
+      CAAR_SK_LD(tn, ld<NTL>(T_nm1 + off))
+      CAAR_SK_LD(dn, ld<NTL>(dp_nm1 + off))
+      CAAR_SK_LD(un, ld<NTL>(reinterpret_cast<const v2*>(vvn0) + off))
+      CAAR_SK_LD(om, ld<NTL>(omega_p + off))
+      CAAR_SK_LD(b3, ld<NTL>(pecnd + off))
+      CAAR_SK_LD(et, ld<NTL>(eta + off))
+#undef CAAR_SK_LD
+#pragma unroll
+      for (int r = 0; r < TPW; ++r) a[r] = b0[r] + b1[r] + b2[r] + b3[r] + g;
+    } else {
+#pragma unroll
+      for (int r = 0; r < TPW; ++r) {
+        const unsigned off = r * 64 + ulane;
+        a[r] = ld<NTL>(dp_n0 + off) + ld<NTL>(T_n0 + off) + ld<NTL>(Qdp + off) + ld<NTL>(pecnd + off) + g;
+        uv[r] = ld<NTL>(reinterpret_cast<const v2*>(vv_n0) + off);
+        um[r] = ld<NTL>(reinterpret_cast<const v2*>(vv_nm1) + off);
+        un[r] = ld<NTL>(reinterpret_cast<const v2*>(vvn0) + off);
+        tn[r] = ld<NTL>(T_nm1 + off);
+        dn[r] = ld<NTL>(dp_nm1 + off);
+        om[r] = ld<NTL>(omega_p + off);
+        et[r] = ld<NTL>(eta + off);
+      }
+    }
+#define CAAR_SK_ST(ptr, expr)                          \
+  _Pragma("unroll") for (int r = 0; r < TPW; ++r) {    \
+    const unsigned off = r * 64 + ulane;               \
+    st<NTS>(ptr + off, expr);                          \
+  }
+    CAAR_SK_ST(reinterpret_cast<v2*>(vv_np1), uv[r] + um[r])
+    CAAR_SK_ST(T_np1, tn[r] + a[r])
+    CAAR_SK_ST(dp_np1, dn[r] + a[r])
+    CAAR_SK_ST(phi, a[r])
+    CAAR_SK_ST(omega_p, om[r] + a[r] * 0.0)
+    CAAR_SK_ST(reinterpret_cast<v2*>(vvn0), un[r])
+    CAAR_SK_ST(eta, et[r] + 0.0)
+#undef CAAR_SK_ST
+    if (w == 0 && lane < PP) eta_last[ulane] = eta_last[ulane] + 0.0;
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < TPW; ++r) {
     const unsigned off = r * 64 + ulane;
@@ -309,6 +365,13 @@ hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, i
       case 19: hipLaunchKernelGGL((traffic_skeleton_np4<72, 2, 1, 1, true, 16, 3>), dim3(num_elems * 3), dim3(192), 0, s, k); break;
       case 20: hipLaunchKernelGGL((traffic_skeleton_np4<72, 1, 1, 1, false, 16, 1>), dim3(num_elems * 18), dim3(64), 0, s, k); break;
       case 22: skel<72, 6, 1, 1, true>(k, num_elems, s); break;   // the default kernel's launch shape (3 waves x 6 tiles), nt
+      // the same shape with each output array's stores issued as one 3 KiB (u, v: 6 KiB) burst per wave (23) and the loads
+      // array-major too (24); 25/26: the same two at 2 waves x 9 tiles (4.5 / 9 KiB bursts)
+      case 23: hipLaunchKernelGGL((traffic_skeleton_np4<72, 6, 1, 1, true, 16, 0, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(192), 0, s, k); break;
+      case 24: hipLaunchKernelGGL((traffic_skeleton_np4<72, 6, 1, 1, true, 16, 0, 2>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(192), 0, s, k); break;
+      case 25: hipLaunchKernelGGL((traffic_skeleton_np4<72, 9, 1, 1, true, 16, 0, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(128), 0, s, k); break;
+      case 26: hipLaunchKernelGGL((traffic_skeleton_np4<72, 9, 1, 1, true, 16, 0, 2>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(128), 0, s, k); break;
+      case 27: skel<72, 9, 1, 1, true>(k, num_elems, s); break;   // 2 waves x 9 tiles, tile-major (the comparator of 25/26)
       case 13: hipLaunchKernelGGL((traffic_skeleton_np4_w16<72, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(576), 0, s, k); break;
       case 14: hipLaunchKernelGGL((traffic_skeleton_np4_w16<72, 0>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(576), 0, s, k); break;
       default: return hipErrorInvalidValue;

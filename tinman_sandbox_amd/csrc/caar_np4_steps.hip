@@ -1,0 +1,89 @@
+// caar_np4_steps.hip — caar_run_steps / caar_launch_steps as ONE launch for NP=4.
+#include <hip/hip_runtime.h>
+
+#include "caar_np4_kernel.h"
+
+namespace caar {
+
+// caar_run_steps as ONE launch (the driver loop main.cpp:113-121 with update_time_levels,
+// data_structures.cpp:174-180, between the calls).  Elements are independent and every lane reads and writes only its own
+// points of its own element — the state it stores at np1 is what it loads as n0 in the next call, the accumulators are its
+// own read-modify-writes — so a workgroup can make all `nsteps` calls for its element back to back with no grid-wide
+// barrier: the launch fill and drain (~14 us of a 10 000-element launch, all of a 64-element one) are paid once per
+// nsteps calls instead of once per call, and from the second call on the element's arrays are still in the L2 / Infinity
+// Cache of the XCD that wrote them (POL = 0: default cache policy; ~95 MB in flight over the chip).  Each call is the same
+// code as caar_np4_kernel's (caar_np4_element): bit-identical to nsteps single launches.
+// The kernel arguments are RE-READ from the kernarg segment at the top of every call (scalar loads through a laundered
+// pointer): kept alive across the loop, the 16 array pointers and the scalars would hold ~70 SGPRs for the whole kernel,
+// the overflow is spilled into VGPR lanes, and the two-workgroup shapes no longer fit 256 VGPRs (measured: 270-283
+// VGPRs that way; as it stands the kernels are at the register count of their single-call twins).
+typedef const __attribute__((address_space(4))) KernelArgs* kernarg_ptr;
+__device__ __forceinline__ KernelArgs reload_args() {
+  kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();  // KernelArgs is the first kernel parameter
+  asm volatile("" : "+s"(kp));
+  KernelArgs k;
+#define CAAR_F(f) k.f = kp->f;
+  CAAR_F(D) CAAR_F(Dinv) CAAR_F(fcor) CAAR_F(spheremp) CAAR_F(metdet) CAAR_F(rmetdet) CAAR_F(dp3d) CAAR_F(v) CAAR_F(T)
+  CAAR_F(phis) CAAR_F(Qdp) CAAR_F(eta_dot_dpdn) CAAR_F(omega_p) CAAR_F(phi) CAAR_F(pecnd) CAAR_F(vn0) CAAR_F(Dvv)
+  CAAR_F(hybi) CAAR_F(vadv) CAAR_F(nets) CAAR_F(nelem) CAAR_F(per_xcd) CAAR_F(cache_count) CAAR_F(n0) CAAR_F(np1)
+  CAAR_F(nm1) CAAR_F(qn0) CAAR_F(qsize_d) CAAR_F(timelevels) CAAR_F(nlev) CAAR_F(dt2) CAAR_F(rrearth) CAAR_F(eta_ave_w)
+  CAAR_F(rv_over_rd_m1) CAAR_F(Rgas) CAAR_F(kappa) CAAR_F(p_top)
+#undef CAAR_F
+  return k;
+}
+static_assert(sizeof(KernelArgs) == 18 * 8 + 12 * 4 + 7 * 8, "reload_args lists every member of KernelArgs");
+
+template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, int PARK>
+__global__ __launch_bounds__((NLEV_T + 3) / 4 / TPW * 64, MINW) void caar_np4_steps_kernel(const KernelArgs k0, int nsteps, int rotate) {
+  __shared__ Np4Lds<NLEV_T, TPW, false, false, 8, PARK> lds;
+  const long long ie_s = element_of_block(k0, blockIdx.x);
+  if (ie_s < 0) return;
+  const bool keep = POL == 2 && element_is_cached(k0, ie_s - k0.nets);
+  int n0 = k0.n0, np1 = k0.np1, nm1 = k0.nm1;
+  for (int s = 0; s < nsteps; ++s) {
+    KernelArgs k = reload_args();
+    k.n0 = n0;
+    k.np1 = np1;
+    k.nm1 = nm1;
+    if constexpr (POL == 2) {
+      if (keep) caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, false, PF, false, false, false, 8, PARK, true>(k, lds);
+      else caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, true, PF, false, false, false, 8, PARK, true>(k, lds);
+    } else {
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, POL == 1, POL == 1, PF, false, false, false, 8, PARK, true>(k, lds);
+    }
+    if (rotate) {  // TestData::update_time_levels
+      const int t = np1;
+      np1 = nm1;
+      nm1 = n0;
+      n0 = t;
+    }
+    wg_barrier<true>();  // the next call re-stages Dvv and the metric terms in LDS: everybody is done reading them
+  }
+}
+
+template <int NLEV, int TPW, int MINW, int POL, int PF, int PARK>
+static hipError_t launch_np4_steps(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t stream) {
+  constexpr int THREADS = (NLEV + 3) / 4 / TPW * 64;
+  if (k.vadv) return hipErrorNotSupported;  // the Eulerian form steps through the graph of single launches
+  const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
+  if (k.qn0 >= 0)
+    hipLaunchKernelGGL((caar_np4_steps_kernel<NLEV, TPW, MINW, true, POL, PF, PARK>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
+  else
+    hipLaunchKernelGGL((caar_np4_steps_kernel<NLEV, TPW, MINW, false, POL, PF, PARK>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
+  return hipGetLastError();
+}
+
+// the instantiations the variant tables of caar_np4.hip point to
+#define CAAR_STEPS(NLEV, TPW, MINW, POL, PF, PARK)                                                                  \
+  hipError_t launch_np4_steps_##NLEV##_##POL(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) { \
+    return launch_np4_steps<NLEV, TPW, MINW, POL, PF, PARK>(k, num_elems, nsteps, rotate, s);                        \
+  }
+CAAR_STEPS(72, 6, 2, 2, 0, 24)
+CAAR_STEPS(72, 6, 2, 1, 0, 24)
+CAAR_STEPS(72, 6, 2, 0, 0, 24)
+CAAR_STEPS(128, 8, 2, 2, 0, 27)
+CAAR_STEPS(128, 8, 2, 1, 0, 27)
+CAAR_STEPS(128, 8, 2, 0, 0, 27)
+#undef CAAR_STEPS
+
+}  // namespace caar

@@ -100,10 +100,13 @@ DeviceSession::DeviceSession(const TestData& data, int ne, int device)
     : DeviceSession(data, 0, ne, device) {}
 
 DeviceSession::DeviceSession(const TestData& data, int first_elem, int ne, int device)
+    : DeviceSession(data, first_elem, ne, device, nullptr) {}
+
+DeviceSession::DeviceSession(const TestData& data, int first_elem, int ne, int device, const CaarPlacement* placement)
     : ctx_(nullptr), num_elems_(ne), first_elem_(first_elem), rsplit_(1), hybi_() {
   const CaarDims d = dims_for(ne);
   if (!caar_supported(d.np, d.nlev)) check(CAAR_EUNSUPPORTED, "caar_supported(np, nlev)");
-  check(caar_create(&ctx_, &d, device), "caar_create");
+  check(caar_create_ex(&ctx_, &d, device, placement), "caar_create_ex");
   upload(data);
 }
 

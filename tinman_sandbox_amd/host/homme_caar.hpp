@@ -22,6 +22,7 @@
 #endif
 
 struct CaarContext;
+struct CaarPlacement;  // include/caar.h: where the device arrays are placed in HBM (NULL: the library's default)
 
 namespace Homme {
 
@@ -50,6 +51,8 @@ class DeviceSession {
   // per GPU when the element range is sharded (elements are independent: no exchange).
   // run()/state_norms() then take Control::nets/nete relative to the slab.
   DeviceSession(const TestData& data, int first_elem, int num_elems, int device);
+  // ... with the placement of the device arrays chosen by the caller (caar_create_ex)
+  DeviceSession(const TestData& data, int first_elem, int num_elems, int device, const CaarPlacement* placement);
   ~DeviceSession();
   DeviceSession(const DeviceSession&) = delete;
   DeviceSession& operator=(const DeviceSession&) = delete;
