@@ -177,6 +177,7 @@ int caar_sphere_operator_range(const CaarDims *dims, const CaarArrays *dev, cons
  *   10 GRADIENT_SPHERE_UPDATE              s  -> v += grad  Dinv                                 K:271-312
  *   11 DIVERGENCE_SPHERE_UPDATE            v  -> s = beta*s + alpha*div   Dinv, metdet, rmetdet  K:363-403
  *   12 VLAPLACE_SPHERE_WK_CARTESIAN_DAMPED v  -> v          as 9, without the rigid-rotation term  K:777-844
+ *   13 LAPLACE_TENSOR_REPLACE              s  -> s in place  as 5; out_dev is input AND output, in_dev is ignored   K:600-637
  * Codes 1, 2, 8, 11 multiply by rmetdet (the pointers_only operators' form, sphere_operators.cpp:85,125)
  * where K: forms 1/metdet on the fly.  The EulerStep functor (EulerStepFunctor.hpp:32-68): caar_euler_step below. */
 enum {
@@ -193,7 +194,8 @@ enum {
   CAAR_OP_GRADIENT_SPHERE_UPDATE = 10,
   CAAR_OP_DIVERGENCE_SPHERE_UPDATE = 11,
   CAAR_OP_VLAPLACE_SPHERE_WK_CARTESIAN_DAMPED = 12,
-  CAAR_OP_COUNT = 13
+  CAAR_OP_LAPLACE_TENSOR_REPLACE = 13,
+  CAAR_OP_COUNT = 14
 };
 /* Per-element geometry, DEVICE pointers to element 0, point-major with the components fastest like
  * CaarArrays: D, Dinv, metinv, tensorVisc [ie][np][np][2][2]; metdet, rmetdet, spheremp, mp [ie][np][np];
@@ -207,7 +209,8 @@ typedef struct CaarOperatorScalars {
   double alpha, beta; /* DIVERGENCE_SPHERE_UPDATE */
   double nu_ratio;    /* VLAPLACE_SPHERE_WK_CONTRA */
 } CaarOperatorScalars;
-/* Asynchronous on `stream`.  in_dev / out_dev 16-byte aligned, not overlapping. */
+/* Asynchronous on `stream`.  in_dev / out_dev 16-byte aligned, not overlapping (code 13 works in place on out_dev; in_dev may
+ * be NULL). */
 int caar_sphere_operator_ex(const CaarDims *dims, const CaarOperatorGeometry *geo, const double *dvv_dev, int which,
                             int e0, int e1, int nlevels, const double *in_dev, double *out_dev,
                             const CaarOperatorScalars *scalars, void *stream);

@@ -151,6 +151,8 @@ void oracle_vlaplace_sphere_wk_contra(int np, const double *v, const double *Dvv
 /* EulerStepFunctor.hpp:32-68, one element: qtens = Qdp(qn0) - dt * div(vstar * Qdp(qn0)) per tracer and level */
 void oracle_euler_step(int np, int nlev, int qsize, int qn0, double dt, const double *vstar, const double *qdp,
                        const double *Dvv, const double *Dinv, const double *metdet, double rrearth, double *qtens);
+void oracle_laplace_tensor_replace(int np, const double *Dvv, const double *Dinv, const double *spheremp,
+                                   const double *tensorVisc, double rrearth, double *laplace);
 
 #ifdef __cplusplus
 }

@@ -121,7 +121,7 @@ class Oracle:
                 "oracle_divergence_sphere_update": [i, f, f, d, d, d, d, f, d],
                 "oracle_k_vorticity_sphere_vector": [i, d, d, d, d, f, d],
                 "oracle_divergence_sphere_wk": [i, d, d, d, d, f, d], "oracle_laplace_simple": [i, d, d, d, d, f, d],
-                "oracle_laplace_tensor": [i, d, d, d, d, d, f, d], "oracle_curl_sphere_wk_testcov": [i, d, d, d, d, f, d],
+                "oracle_laplace_tensor": [i, d, d, d, d, d, f, d], "oracle_laplace_tensor_replace": [i, d, d, d, d, f, d], "oracle_curl_sphere_wk_testcov": [i, d, d, d, d, f, d],
                 "oracle_grad_sphere_wk_testcov": [i, d, d, d, d, d, d, f, d],
                 "oracle_vlaplace_sphere_wk_cartesian": [i, d, d, d, d, d, d, f, i, d],
                 "oracle_vlaplace_sphere_wk_contra": [i, d, d, d, d, d, d, d, d, f, f, d],
@@ -214,6 +214,7 @@ SPHERE_OPS = {
     "divergence_sphere_wk": (True, False, ("Dinv", "spheremp")),
     "laplace_simple": (False, False, ("Dinv", "spheremp")),
     "laplace_tensor": (False, False, ("Dinv", "spheremp", "tensorVisc")),
+    "laplace_tensor_replace": (False, False, ("Dinv", "spheremp", "tensorVisc")),
     "curl_sphere_wk_testcov": (False, True, ("D", "mp")),
     "grad_sphere_wk_testcov": (False, True, ("D", "mp", "metinv", "metdet")),
     "vlaplace_sphere_wk_cartesian": (True, True, ("Dinv", "spheremp", "tensorVisc", "vec_sph2cart")),
@@ -251,6 +252,9 @@ def sphere_op(O, name, x, Dvv, geo, rrearth, out=None, alpha=1.0, beta=0.0, nu_r
         L.oracle_laplace_simple(np_, P(x), P(Dvv), P(g[0]), P(g[1]), rrearth, P(res))
     elif name == "laplace_tensor":
         L.oracle_laplace_tensor(np_, P(x), P(Dvv), P(g[0]), P(g[1]), P(g[2]), rrearth, P(res))
+    elif name == "laplace_tensor_replace":  # in place: the result replaces (a copy of) the input
+        res = np.array(x, dtype=np.float64, order="C")
+        L.oracle_laplace_tensor_replace(np_, P(Dvv), P(g[0]), P(g[1]), P(g[2]), rrearth, P(res))
     elif name == "curl_sphere_wk_testcov":
         L.oracle_curl_sphere_wk_testcov(np_, P(x), P(Dvv), P(g[0]), P(g[1]), rrearth, P(res))
     elif name == "grad_sphere_wk_testcov":

@@ -8,7 +8,8 @@
  *     compute_and_apply_rhs_test/cxx/level_vectorized_ppscan/SphereOperators.hpp   (cited as K:)
  *   gradient_sphere K:229-269, gradient_sphere_update K:271-312, divergence_sphere K:315-358,
  *   divergence_sphere_update K:363-403, vorticity_sphere_vector K:452-490, divergence_sphere_wk
- *   K:494-534, laplace_simple K:538-550, laplace_tensor K:556-596, curl_sphere_wk_testcov K:640-690,
+ *   K:494-534, laplace_simple K:538-550, laplace_tensor K:556-596, laplace_tensor_replace K:600-637,
+ *   curl_sphere_wk_testcov K:640-690,
  *   grad_sphere_wk_testcov K:694-770, vlaplace_sphere_wk_cartesian_reduced K:849-915,
  *   vlaplace_sphere_wk_contra K:938-993.
  *
@@ -166,6 +167,21 @@ void oracle_laplace_tensor(int np, const double *s, const double *Dvv, const dou
       KV(t, 1, igp, jgp) = KT(tensorVisc, 0, 1, igp, jgp) * KV(g, 0, igp, jgp) + KT(tensorVisc, 1, 1, igp, jgp) * KV(g, 1, igp, jgp); /* K:578-579 */
     }
   oracle_divergence_sphere_wk(np, t, Dvv, Dinv, spheremp, rrearth, lap); /* K:595 */
+}
+
+/* K:600-637 laplace_tensor_replace: "a version of laplace_tensor where input is replaced by output" — the same three
+ * steps (K:609 gradient_sphere of `laplace`, K:616-619 tensorVisc times the gradient, K:636 divergence_sphere_wk back
+ * into `laplace`); the whole field is read before any of it is overwritten. */
+void oracle_laplace_tensor_replace(int np, const double *Dvv, const double *Dinv, const double *spheremp,
+                                   const double *tensorVisc, double rrearth, double *laplace) {
+  double g[2 * MAXNP * MAXNP], t[2 * MAXNP * MAXNP];
+  oracle_k_gradient_sphere(np, laplace, Dvv, Dinv, rrearth, g); /* K:609 */
+  for (int igp = 0; igp < np; ++igp)
+    for (int jgp = 0; jgp < np; ++jgp) {
+      KV(t, 0, igp, jgp) = KT(tensorVisc, 0, 0, igp, jgp) * KV(g, 0, igp, jgp) + KT(tensorVisc, 1, 0, igp, jgp) * KV(g, 1, igp, jgp); /* K:616-617 */
+      KV(t, 1, igp, jgp) = KT(tensorVisc, 0, 1, igp, jgp) * KV(g, 0, igp, jgp) + KT(tensorVisc, 1, 1, igp, jgp) * KV(g, 1, igp, jgp); /* K:618-619 */
+    }
+  oracle_divergence_sphere_wk(np, t, Dvv, Dinv, spheremp, rrearth, laplace); /* K:636 */
 }
 
 /* K:640-690 curl_sphere_wk_testcov */

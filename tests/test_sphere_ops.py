@@ -101,6 +101,9 @@ def test_compositions(oracle, np_):
     ident = dict(e)
     ident["tensorVisc"] = np.broadcast_to(np.eye(2), (np_, np_, 2, 2)).copy()
     assert np.array_equal(po.sphere_op(oracle, "laplace_tensor", s, Dvv, ident, RR), lap)
+    # K:600-637: the in-place form gives what the out-of-place one gives, and leaves nothing of the input behind
+    assert np.array_equal(po.sphere_op(oracle, "laplace_tensor_replace", s, Dvv, e, RR),
+                          po.sphere_op(oracle, "laplace_tensor", s, Dvv, e, RR))
     # a constant field has no gradient, hence no Laplacian — with the derivative matrix in HOMME's orientation
     # Dvv(i, l) = l_i'(x_l).  (The reference's standalone drivers fill Dvv the other way round,
     # data_structures.cpp:152-162 / main.F90:83-96: there the "gradient" of a constant is not zero, which is
@@ -223,7 +226,8 @@ def _oracle_all(oracle, name, x, Dvv, g, e0, **kw):
 
 HIP_TO_ORACLE = {  # HIP operator name -> (oracle operator name, oracle kwargs)
     "divergence_sphere_wk": ("divergence_sphere_wk", {}), "laplace_simple": ("laplace_simple", {}),
-    "laplace_tensor": ("laplace_tensor", {}), "curl_sphere_wk_testcov": ("curl_sphere_wk_testcov", {}),
+    "laplace_tensor": ("laplace_tensor", {}), "laplace_tensor_replace": ("laplace_tensor_replace", {}),
+    "curl_sphere_wk_testcov": ("curl_sphere_wk_testcov", {}),
     "grad_sphere_wk_testcov": ("grad_sphere_wk_testcov", {}),
     "vlaplace_sphere_wk_contra": ("vlaplace_sphere_wk_contra", dict(nu_ratio=1.75)),
     "vlaplace_sphere_wk_cartesian": ("vlaplace_sphere_wk_cartesian", dict(undamp_rr=1)),

@@ -87,6 +87,7 @@ SPHERE_OPERATORS = {
     "vlaplace_sphere_wk_contra": (8, True, True), "vlaplace_sphere_wk_cartesian": (9, True, True),
     "gradient_sphere_update": (10, False, True), "divergence_sphere_update": (11, True, False),
     "vlaplace_sphere_wk_cartesian_damped": (12, True, True),
+    "laplace_tensor_replace": (13, False, False),   # in place: `field` is overwritten and returned
 }
 
 
@@ -645,6 +646,10 @@ def sphere_operator_ex(name, field, geometry, Dvv, rrearth, out=None, alpha=1.0,
     ne, nl, np_ = f.shape[0], f.shape[1], f.shape[2]
     assert tuple(f.shape) == ((ne, nl, np_, np_, 2) if vin else (ne, nl, np_, np_))
     oshape = (ne, nl, np_, np_, 2) if vout else (ne, nl, np_, np_)
+    if name == "laplace_tensor_replace":  # K:600-637: the input field is replaced by the result
+        if f.data_ptr() != field.data_ptr():
+            raise CaarError("laplace_tensor_replace works in place and needs a contiguous field")
+        out = f
     if out is None:
         out = torch.empty(oshape, dtype=torch.float64, device=f.device)
     assert tuple(out.shape) == oshape and out.is_contiguous() and out.dtype == torch.float64

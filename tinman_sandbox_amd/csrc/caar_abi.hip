@@ -463,8 +463,9 @@ int caar_sphere_operator_range(const CaarDims* dims, const CaarArrays* dev, cons
 int caar_sphere_operator_ex(const CaarDims* dims, const CaarOperatorGeometry* geo, const double* dvv_dev, int which,
                             int e0, int e1, int nlevels, const double* in_dev, double* out_dev,
                             const CaarOperatorScalars* sc, void* stream) {
-  if (!dims || !geo || !dvv_dev || !in_dev || !out_dev || !sc || nlevels < 0) return CAAR_EINVAL;
+  if (!dims || !geo || !dvv_dev || !out_dev || !sc || nlevels < 0) return CAAR_EINVAL;
   if (which < 0 || which >= CAAR_OP_COUNT) return CAAR_EINVAL;
+  if (!in_dev && which != CAAR_OP_LAPLACE_TENSOR_REPLACE) return CAAR_EINVAL;  // the in-place form reads out_dev
   if (e0 < 0 || e1 > dims->num_elems || e0 > e1) return CAAR_EINVAL;
   if (dims->np != 4 && dims->np != 8) return CAAR_EUNSUPPORTED;
   if ((((size_t)in_dev) | ((size_t)out_dev)) & 15) return CAAR_EINVAL;

@@ -39,6 +39,8 @@ CAAR_STEPS_DECL(128, 2);
 CAAR_STEPS_DECL(128, 1);
 CAAR_STEPS_DECL(128, 0);
 #undef CAAR_STEPS_DECL
+hipError_t launch_np4_steps_72_auto(const KernelArgs&, int, int, int, hipStream_t);   // cache policy by footprint
+hipError_t launch_np4_steps_128_auto(const KernelArgs&, int, int, int, hipStream_t);
 
 // explicit instantiations + launchers --------------------------------------------------
 static int cu_count() {
@@ -87,7 +89,7 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
-    {"caar_np4_kernel<72, 6, 1, true, 2, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU), hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<72, 6, 1, 2, 0, 0, false, 6, 2, 0, 0, 43>, true, launch_np4_steps_72_2},
+    {"caar_np4_kernel<72, 6, 1, true, 2, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU), hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<72, 6, 1, 2, 0, 0, false, 6, 2, 0, 0, 43>, true, launch_np4_steps_72_auto},
     {"caar_np4_kernel<72, 6, 1, true, 1, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU), nt (all streaming), update loads one tile ahead", launch_np4<72, 6, 1, true, 0, 0, false, 6, 2, 0, 0, 43>, false, launch_np4_steps_72_1},
     {"caar_np4_kernel<72, 2, 1, true, 2, 1, false, false, false, 8, 0>", "9 waves x 2 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<72, 2, 1, 2, 1, 0, false, 3, 2, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, false, false, 8, 0>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},
@@ -106,7 +108,7 @@ KernelVariant kNp4Nlev72[] = {
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
-    {"caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS between the phases, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<128, 8, 2, 2, 0, 0, false, 4, 2, 0, 27, 32>, true, launch_np4_steps_128_2},
+    {"caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS between the phases, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<128, 8, 2, 2, 0, 0, false, 4, 2, 0, 27, 32>, true, launch_np4_steps_128_auto},
     {"caar_np4_kernel<128, 8, 2, true, 1, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS, nt (all streaming), update loads one tile ahead", launch_np4<128, 8, 2, true, 0, 0, false, 4, 2, 0, 27, 32>, false, launch_np4_steps_128_1},
     {"caar_np4_kernel<128, 4, 2, true, 2, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<128, 4, 2, 2, 1, 0, false, 8, 1, 0>},
     {"caar_np4_kernel<128, 4, 2, true, 1, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 1, 0>},

@@ -86,4 +86,16 @@ CAAR_STEPS(128, 8, 2, 1, 0, 27)
 CAAR_STEPS(128, 8, 2, 0, 0, 27)
 #undef CAAR_STEPS
 
+// What the default variants use: the cache policy of the step loop by footprint.  Data sets well beyond the 256 MB
+// Infinity Cache run fastest with the default policy for everything (a call's outputs are the next call's inputs and are
+// still on chip: 7.5 TB/s algorithmic at 10 000 elements against 7.2 hybrid and 6.4 all-streaming); smaller ones with the
+// hybrid policy, whose streaming accesses leave the cache to the accumulators (7.8 against 7.4 at 4 096 elements).
+// profiles/r03/steps_bench_72.log, steps_bench_128.log.
+hipError_t launch_np4_steps_72_auto(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) {
+  return num_elems >= 6500 ? launch_np4_steps_72_0(k, num_elems, nsteps, rotate, s) : launch_np4_steps_72_2(k, num_elems, nsteps, rotate, s);
+}
+hipError_t launch_np4_steps_128_auto(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) {
+  return num_elems >= 3700 ? launch_np4_steps_128_0(k, num_elems, nsteps, rotate, s) : launch_np4_steps_128_2(k, num_elems, nsteps, rotate, s);
+}
+
 }  // namespace caar

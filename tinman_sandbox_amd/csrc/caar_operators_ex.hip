@@ -2,7 +2,7 @@
 //
 // Reference: cxx/level_vectorized_ppscan/SphereOperators.hpp (K:) — gradient_sphere_update K:271-312,
 // divergence_sphere_update K:363-403, vorticity_sphere_vector K:452-490, divergence_sphere_wk K:494-534,
-// laplace_simple K:538-550, laplace_tensor K:556-596, curl_sphere_wk_testcov K:640-690,
+// laplace_simple K:538-550, laplace_tensor K:556-596, laplace_tensor_replace K:600-637, curl_sphere_wk_testcov K:640-690,
 // grad_sphere_wk_testcov K:694-770, vlaplace_sphere_wk_cartesian(_reduced) K:777-915,
 // vlaplace_sphere_wk_contra K:938-993.  Parity unpinned (the reference never builds or calls them): see
 // oracle/sphere_ops_oracle.c and tests/test_sphere_ops.py for what pins the oracle they are tested against.
@@ -116,7 +116,10 @@ enum {
   OP_CURL_WK = CAAR_OP_CURL_SPHERE_WK_TESTCOV, OP_GRAD_WK = CAAR_OP_GRAD_SPHERE_WK_TESTCOV,
   OP_VLAP_CONTRA = CAAR_OP_VLAPLACE_SPHERE_WK_CONTRA, OP_VLAP_CART = CAAR_OP_VLAPLACE_SPHERE_WK_CARTESIAN,
   OP_GRAD_UPD = CAAR_OP_GRADIENT_SPHERE_UPDATE, OP_DIV_UPD = CAAR_OP_DIVERGENCE_SPHERE_UPDATE,
-  OP_VLAP_CART_DAMPED = CAAR_OP_VLAPLACE_SPHERE_WK_CARTESIAN_DAMPED
+  OP_VLAP_CART_DAMPED = CAAR_OP_VLAPLACE_SPHERE_WK_CARTESIAN_DAMPED,
+  // K:600-637 "a version of laplace_tensor where input is replaced by output": every lane reads its own point of a.out,
+  // the NP x NP exchange happens in registers, and the same lane stores the result to the same place
+  OP_LAP_T_REPL = CAAR_OP_LAPLACE_TENSOR_REPLACE
 };
 __host__ __device__ constexpr bool op_vector_in(int w) {
   return w == OP_DIV || w == OP_VORT || w == OP_DIV_WK || w == OP_VLAP_CONTRA || w == OP_VLAP_CART ||
@@ -157,14 +160,15 @@ __global__ __launch_bounds__(256) void sphere_operator_ex_kernel(const OpArgs a)
   const double rr = a.rrearth;
 
   constexpr bool NEED_D = WHICH == OP_VORT || WHICH == OP_CURL_WK || WHICH == OP_GRAD_WK || WHICH == OP_VLAP_CONTRA;
+  constexpr bool IN_PLACE = WHICH == OP_LAP_T_REPL;
   constexpr bool NEED_DINV = WHICH != OP_VORT && WHICH != OP_CURL_WK && WHICH != OP_GRAD_WK;
   constexpr bool NEED_METDET = WHICH == OP_DIV || WHICH == OP_GRAD_WK || WHICH == OP_VLAP_CONTRA || WHICH == OP_DIV_UPD;
   constexpr bool NEED_RMETDET = WHICH == OP_DIV || WHICH == OP_VORT || WHICH == OP_VLAP_CONTRA || WHICH == OP_DIV_UPD;
-  constexpr bool NEED_SPHEREMP = WHICH == OP_DIV_WK || WHICH == OP_LAP || WHICH == OP_LAP_T || WHICH == OP_VLAP_CONTRA ||
+  constexpr bool NEED_SPHEREMP = WHICH == OP_DIV_WK || WHICH == OP_LAP || WHICH == OP_LAP_T || WHICH == OP_LAP_T_REPL || WHICH == OP_VLAP_CONTRA ||
                                  WHICH == OP_VLAP_CART || WHICH == OP_VLAP_CART_DAMPED;
   constexpr bool NEED_MP = WHICH == OP_CURL_WK || WHICH == OP_GRAD_WK || WHICH == OP_VLAP_CONTRA;
   constexpr bool NEED_METINV = WHICH == OP_GRAD_WK || WHICH == OP_VLAP_CONTRA;
-  constexpr bool NEED_TV = WHICH == OP_LAP_T || WHICH == OP_VLAP_CART || WHICH == OP_VLAP_CART_DAMPED;
+  constexpr bool NEED_TV = WHICH == OP_LAP_T || WHICH == OP_LAP_T_REPL || WHICH == OP_VLAP_CART || WHICH == OP_VLAP_CART_DAMPED;
   constexpr bool NEED_S2C = WHICH == OP_VLAP_CART || WHICH == OP_VLAP_CART_DAMPED;
 
   for (int e = blockIdx.x; e < a.ne; e += gridDim.x) {
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void sphere_operator_ex_kernel(const OpArgs a)
           const dbl2 t = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(a.in) + o);
           v = {t.x, t.y};
         } else {
-          s = __builtin_nontemporal_load(a.in + o);
+          s = __builtin_nontemporal_load((IN_PLACE ? a.out : a.in) + o);
         }
       }
       double rs = 0;
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256) void sphere_operator_ex_kernel(const OpArgs a)
       else if constexpr (WHICH == OP_VORT) rs = op_vorticity(x, D, rmetdet, rr, v);
       else if constexpr (WHICH == OP_DIV_WK) rs = op_divergence_wk(x, Dinv, spheremp, rr, v);
       else if constexpr (WHICH == OP_LAP) rs = op_laplace<false>(x, Dinv, spheremp, tv, rr, s);
-      else if constexpr (WHICH == OP_LAP_T) rs = op_laplace<true>(x, Dinv, spheremp, tv, rr, s);
+      else if constexpr (WHICH == OP_LAP_T || WHICH == OP_LAP_T_REPL) rs = op_laplace<true>(x, Dinv, spheremp, tv, rr, s);
       else if constexpr (WHICH == OP_CURL_WK) rv = op_curl_wk_testcov(x, D, mp, rr, s);
       else if constexpr (WHICH == OP_GRAD_WK) rv = op_grad_wk_testcov(x, D, mp, metinv, metdet, rr, s);
       else if constexpr (WHICH == OP_VLAP_CONTRA) {  // K:938-993
@@ -257,6 +261,7 @@ static hipError_t launch_ex_np(int which, const OpArgs& a, hipStream_t s) {
     CAAR_OP_CASE(OP_GRAD) CAAR_OP_CASE(OP_DIV) CAAR_OP_CASE(OP_VORT) CAAR_OP_CASE(OP_DIV_WK) CAAR_OP_CASE(OP_LAP)
     CAAR_OP_CASE(OP_LAP_T) CAAR_OP_CASE(OP_CURL_WK) CAAR_OP_CASE(OP_GRAD_WK) CAAR_OP_CASE(OP_VLAP_CONTRA)
     CAAR_OP_CASE(OP_VLAP_CART) CAAR_OP_CASE(OP_GRAD_UPD) CAAR_OP_CASE(OP_DIV_UPD) CAAR_OP_CASE(OP_VLAP_CART_DAMPED)
+    CAAR_OP_CASE(OP_LAP_T_REPL)
     default: return hipErrorInvalidValue;
   }
 #undef CAAR_OP_CASE
@@ -339,7 +344,7 @@ unsigned sphere_operator_ex_needs(int which) {
     case OP_DIV: case OP_DIV_UPD: return gDinv | gMetdet | gRmetdet;
     case OP_VORT: return gD | gRmetdet;
     case OP_DIV_WK: case OP_LAP: return gDinv | gSpheremp;
-    case OP_LAP_T: return gDinv | gSpheremp | gTv;
+    case OP_LAP_T: case OP_LAP_T_REPL: return gDinv | gSpheremp | gTv;
     case OP_CURL_WK: return gD | gMp;
     case OP_GRAD_WK: return gD | gMp | gMetinv | gMetdet;
     case OP_VLAP_CONTRA: return gD | gDinv | gMp | gSpheremp | gMetinv | gMetdet | gRmetdet;
