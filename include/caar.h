@@ -110,6 +110,12 @@ typedef struct CaarParams {
 int caar_supported(int np, int nlev);
 /* CAAR_ABI_VERSION the library was built with. */
 int caar_abi_version(void);
+/* Debug builds (libcaar_hip_debug.so, compiled with -DCAAR_DEBUG: `python -m tinman_sandbox_amd.build --debug`): the
+ * reference's only hot-path assertion, check_dp3d (level_vectorized_ppscan/CaarFunctor.hpp:82-97: dp3d(np1) > 0 under
+ * !NDEBUG).  The kernels count every dp3d(np1) they store that is not positive (a counter, not a trap: a trapping kernel
+ * takes the GPU down); this returns the count on the current device since the start / the last reset, after waiting for
+ * the device.  -1 in a release build, -2 if the HIP calls fail. */
+long long caar_debug_dp3d_violations(int reset);
 /* Number of HIP devices visible to the process (0 if none / no driver). */
 int caar_device_count(void);
 /* Static text for a return code. */
@@ -382,6 +388,10 @@ int caar_download(CaarContext *ctx, const CaarArrays *host, int e0, int e1, int 
  * (see "Fortran-layout ingest / egress" above); the re-layout happens on the device. */
 int caar_upload_f90(CaarContext *ctx, const CaarArrays *f90_host, int e0, int e1);
 int caar_download_f90(CaarContext *ctx, const CaarArrays *f90_host, int e0, int e1, int all_arrays);
+/* caar_upload_f90 for a subset of the arrays: bit i of array_mask = array i in CaarArrays member order (pointers of
+ * the others may be NULL).  A host that calls the path on arrays it owns uploads the constant geometry once and the
+ * fields it changed each call (host/fortran/routine_mod_hip.F90). */
+int caar_upload_f90_arrays(CaarContext *ctx, const CaarArrays *f90_host, int e0, int e1, unsigned array_mask);
 /* Enqueue one compute_and_apply_rhs on the context's device arrays
  * (params->Dvv is read from host memory and cached on the device). */
 int caar_run(CaarContext *ctx, const CaarParams *params);

@@ -502,3 +502,59 @@ def test_context_api_allocates_through_the_placed_allocator(oracle):
     for n in cases.OUTPUT_NAMES:
         assert cases.scaled_err(arrs[n][:4], want[n][:4]) <= 1e-12, n
         assert np.array_equal(arrs[n][4:], want[n][4:]), n
+
+
+_DEBUG_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch
+import tinman_sandbox_amd as tsa
+import cases
+from oracle import pyoracle as po   # checker only
+lib = tsa.library().lib
+assert tsa.caar.LIB_PATH.endswith("libcaar_hip_debug.so")
+total = 0
+for name in ("np4_nlev72_closed", "np4_nlev128_closed", "np8_nlev72_closed"):
+    arrs, Dvv, sc = cases.make_case(name)
+    # healthy state: nothing to report, same results as ever
+    want = cases.copy_arrays(arrs)
+    po.Oracle().compute_and_apply_rhs(want, Dvv, sc)
+    data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    tsa.compute_and_apply_rhs(data)
+    assert lib.caar_debug_dp3d_violations(0) == total, name
+    got = data.arrays.to_numpy()
+    for n in cases.OUTPUT_NAMES:
+        assert cases.scaled_err(got[n], want[n]) <= 1e-12, (name, n)
+    # a layer thickness that goes non-positive at np1 (dp3d(nm1) far below zero in a few places)
+    bad = cases.copy_arrays(arrs)
+    bad["elem_state_dp3d"][0, sc["nm1"], 3:5] = -1.0e6
+    want = cases.copy_arrays(bad)
+    po.Oracle().compute_and_apply_rhs(want, Dvv, sc)
+    expect = int((want["elem_state_dp3d"][sc["nets"]:sc["nete"], sc["np1"]] <= 0).sum())
+    assert expect > 0
+    data = tsa.TestData.from_numpy(bad, Dvv, sc, device="cuda")
+    tsa.compute_and_apply_rhs(data)
+    total += expect
+    assert lib.caar_debug_dp3d_violations(0) == total, (name, lib.caar_debug_dp3d_violations(0), total)
+# the step-loop kernel has its own counter
+arrs, Dvv, sc = cases.make_case("np4_nlev72_closed")
+arrs["elem_state_dp3d"][1, sc["nm1"], 7] = -1.0e6
+data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+tsa.compute_and_apply_rhs_steps(data, 1, True)
+assert lib.caar_debug_dp3d_violations(1) > total
+assert lib.caar_debug_dp3d_violations(0) == 0     # reset
+print("DEBUG-BUILD-OK", total)
+"""
+
+
+def test_debug_build_counts_nonpositive_layer_thickness(tmp_path):
+    """-DCAAR_DEBUG (libcaar_hip_debug.so): the reference's only hot-path assertion, check_dp3d
+    (level_vectorized_ppscan/CaarFunctor.hpp:82-97: dp3d(np1) > 0), as a device-side counter — as many violations as the
+    oracle's result has non-positive dp3d(np1) entries, none on healthy data, same results; the release build says -1."""
+    import subprocess
+    assert tsa.library().lib.caar_debug_dp3d_violations(0) == -1
+    script = tmp_path / "debug_build.py"
+    script.write_text(_DEBUG_SCRIPT)
+    env = dict(os.environ, CAAR_LIBRARY="debug")
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "DEBUG-BUILD-OK" in r.stdout, (r.stdout + r.stderr)[-3000:]

@@ -32,20 +32,29 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def build_library(force=False, verbose=False, jobs=4):
+LIB_DEBUG = os.path.join(CSRC, "libcaar_hip_debug.so")
+# the translation units -DCAAR_DEBUG changes (the CAAR kernels and the ABI entry that reads their counters)
+DEBUG_SOURCES = ("caar_np4.hip", "caar_np4_steps.hip", "caar_np8.hip", "caar_abi.hip")
+
+
+def build_library(force=False, verbose=False, jobs=4, debug=False):
     """One object per .hip source (only stale ones are recompiled, `jobs` at a time), then one
-    link: editing one kernel file costs one compile, not seven."""
+    link: editing one kernel file costs one compile, not seven.  debug: libcaar_hip_debug.so, the same
+    library with the kernels compiled with -DCAAR_DEBUG (the reference's check_dp3d as a device-side
+    counter, include/caar.h caar_debug_dp3d_violations); the other objects are the release ones."""
     from concurrent.futures import ThreadPoolExecutor
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
         os.path.join(HERE, "..", "include", "caar.h")]
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
+    LIB = LIB_DEBUG if debug else globals()["LIB"]
 
     def compile_one(name):
-        src, obj = os.path.join(CSRC, name), os.path.join(objdir, name.replace(".hip", ".o"))
+        dbg = debug and name in DEBUG_SOURCES
+        src, obj = os.path.join(CSRC, name), os.path.join(objdir, name.replace(".hip", ".debug.o" if dbg else ".o"))
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc()] + flags + ["-c", src, "-o", obj]
+            cmd = [hipcc()] + flags + (["-DCAAR_DEBUG"] if dbg else []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
@@ -110,8 +119,10 @@ def build_fortran_driver(force=False, verbose=False):
     return exe
 
 
-def build_all(force=False, verbose=False):
+def build_all(force=False, verbose=False, debug=True):
     lib = build_library(force, verbose)
+    if debug:
+        build_library(force, verbose, debug=True)
     for np_, nlev in ((4, 72), (4, 128), (8, 72)):
         build_host_driver(force, verbose, np_, nlev)
     build_fortran_driver(force, verbose)
@@ -119,4 +130,8 @@ def build_all(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build_all(verbose=True))
+    import sys
+    if "--debug" in sys.argv[1:]:
+        print(build_library(verbose=True, debug=True))
+    else:
+        print(build_all(verbose=True))

@@ -19,7 +19,9 @@ import numpy as np
 import torch  # imported BEFORE the HIP library is loaded so both share one HIP runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcaar_hip.so")
+# CAAR_LIBRARY=debug loads the -DCAAR_DEBUG build (dp3d(np1) > 0 checked by the kernels, caar_debug_dp3d_violations)
+LIB_PATH = os.path.join(_HERE, "csrc", "libcaar_hip_debug.so" if os.environ.get("CAAR_LIBRARY", "") == "debug"
+                        else "libcaar_hip.so")
 
 # member order of Homme::Arrays (data_structures.hpp:18-44) == CaarArrays
 ARRAY_NAMES = (
@@ -94,10 +96,10 @@ SPHERE_OPERATORS = {
 class CaarLibrary:
     """ctypes view of libcaar_hip.so; every symbol of include/caar.h is bound here."""
 
-    SYMBOLS = ("caar_supported", "caar_abi_version", "caar_device_count", "caar_strerror", "caar_array_len",
+    SYMBOLS = ("caar_supported", "caar_abi_version", "caar_debug_dp3d_violations", "caar_device_count", "caar_strerror", "caar_array_len",
                "caar_algorithmic_bytes", "caar_launch", "caar_launch_steps", "caar_launch_state_norms", "caar_sphere_operator", "caar_sphere_operator_range", "caar_sphere_operator_ex", "caar_euler_step", "caar_preq_hydrostatic", "caar_preq_omega_ps", "caar_sphere_operator_host", "caar_preq_hydrostatic_host", "caar_preq_omega_ps_host", "caar_reciprocal",
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
-               "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_selected_variant", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_stream_copy_tuned", "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_arrays_alloc", "caar_arrays_alloc_ex", "caar_arrays_free", "caar_arrays_placement", "caar_create", "caar_create_ex", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_download_f90",
+               "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_selected_variant", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_stream_copy_tuned", "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_arrays_alloc", "caar_arrays_alloc_ex", "caar_arrays_free", "caar_arrays_placement", "caar_create", "caar_create_ex", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_upload_f90_arrays", "caar_download_f90",
                "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
                "caar_time_runs", "caar_run_steps", "caar_set_fused_steps", "caar_get_fused_steps", "caar_map_host", "caar_run_mapped", "caar_unmap_host")
 
@@ -111,6 +113,8 @@ class CaarLibrary:
             getattr(L, s)  # AttributeError if the library does not export it
         vp = C.c_void_p
         L.caar_supported.argtypes = [C.c_int, C.c_int]
+        L.caar_debug_dp3d_violations.argtypes = [C.c_int]
+        L.caar_debug_dp3d_violations.restype = C.c_longlong
         L.caar_strerror.argtypes = [C.c_int]
         L.caar_strerror.restype = C.c_char_p
         L.caar_array_len.argtypes = [C.POINTER(_CaarDims), C.c_int]
@@ -170,6 +174,7 @@ class CaarLibrary:
         L.caar_upload.argtypes = [vp, C.POINTER(_CaarArrays), C.c_int, C.c_int]
         L.caar_download.argtypes = [vp, C.POINTER(_CaarArrays), C.c_int, C.c_int, C.c_int]
         L.caar_upload_f90.argtypes = [vp, C.POINTER(_CaarArrays), C.c_int, C.c_int]
+        L.caar_upload_f90_arrays.argtypes = [vp, C.POINTER(_CaarArrays), C.c_int, C.c_int, C.c_uint]
         L.caar_download_f90.argtypes = [vp, C.POINTER(_CaarArrays), C.c_int, C.c_int, C.c_int]
         L.caar_run.argtypes = [vp, C.POINTER(_CaarParams)]
         L.caar_sync.argtypes = [vp]

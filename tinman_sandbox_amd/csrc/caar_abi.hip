@@ -46,6 +46,11 @@ hipError_t launch_layout(double* dst, const double* src, size_t n, int np, int n
                          int qdp_outer, bool to_caar, hipStream_t s);
 hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t stream);
 hipError_t launch_traffic_skeleton_np8(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t stream);
+#ifdef CAAR_DEBUG
+long long debug_dp3d_count_np4(int reset);
+long long debug_dp3d_count_np4_steps(int reset);
+long long debug_dp3d_count_np8(int reset);
+#endif
 
 // `selected` is the only mutable member: atomic, read ONCE per launch (launch_choice), so a
 // caar_select_variant racing with launches on other threads is well defined (each launch uses
@@ -196,6 +201,18 @@ int caar_abi_version(void) { return CAAR_ABI_VERSION; }
 int caar_device_count(void) {
   int n = 0;
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+long long caar_debug_dp3d_violations(int reset) {
+#ifdef CAAR_DEBUG
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  const long long a = caar::debug_dp3d_count_np4(reset), b = caar::debug_dp3d_count_np4_steps(reset),
+                  c = caar::debug_dp3d_count_np8(reset);
+  return (a < 0 || b < 0 || c < 0) ? -2 : a + b + c;
+#else
+  (void)reset;
+  return -1;  // not a debug build
+#endif
 }
 
 int caar_supported(int np, int nlev) { return caar::find_config(np, nlev) != nullptr; }
@@ -811,7 +828,8 @@ int caar_download(CaarContext* c, const CaarArrays* host, int e0, int e1, int al
 // Fortran-ordered HOST arrays <-> the context's device arrays: each array goes through one
 // device staging buffer (H2D copy + layout kernel, or layout kernel + D2H copy), all ordered
 // on the context stream, so the staging buffer is reused array after array.
-static int f90_transfer(CaarContext* c, const CaarArrays* f90_host, int e0, int e1, bool upload, bool mutated_only) {
+static int f90_transfer(CaarContext* c, const CaarArrays* f90_host, int e0, int e1, bool upload, bool mutated_only,
+                        unsigned mask = 0xffffu) {
   if (!c || !f90_host || e0 < 0 || e1 > c->dims.num_elems || e0 > e1) return CAAR_EINVAL;
   HIP_TRY(hipSetDevice(c->device));
   if (!c->stage_dev) {
@@ -824,7 +842,7 @@ static int f90_transfer(CaarContext* c, const CaarArrays* f90_host, int e0, int 
   for (int i = 0; i < CAAR_NUM_ARRAYS; ++i) {
     bool wanted = !mutated_only;
     for (int m : kMutated) wanted = wanted || m == i;
-    if (!wanted) continue;
+    if (!wanted || !((mask >> i) & 1u)) continue;
     double* h = *array_slot(f90_host, i);
     if (!h) return CAAR_EINVAL;
     const long long per = caar_array_len(&c->dims, i) / c->dims.num_elems;
@@ -846,6 +864,10 @@ static int f90_transfer(CaarContext* c, const CaarArrays* f90_host, int e0, int 
 
 int caar_upload_f90(CaarContext* c, const CaarArrays* f90_host, int e0, int e1) {
   return f90_transfer(c, f90_host, e0, e1, true, false);
+}
+
+int caar_upload_f90_arrays(CaarContext* c, const CaarArrays* f90_host, int e0, int e1, unsigned array_mask) {
+  return f90_transfer(c, f90_host, e0, e1, true, false, array_mask & 0xffffu);
 }
 
 int caar_download_f90(CaarContext* c, const CaarArrays* f90_host, int e0, int e1, int all_arrays) {

@@ -50,9 +50,13 @@ struct KernelArgs {
 // (blockIdx % 8 shares an XCD; MI355X_MICROARCH.md), so with the plain mapping (default)
 // the co-resident workgroups of all XCDs work on ~256 CONSECUTIVE elements: the chip
 // sweeps every array front to back.  The chunked mapping gives XCD x the contiguous
-// element range [x*per_xcd, (x+1)*per_xcd) (one eighth of the pages per L2/TLB) — it
-// measured 2-4 % SLOWER (profiles/r01/kbench_xcd_mapping.log; DRAM locality wins over
-// TLB reach), so it is kept only as a knob.  Speed only — any placement computes the
+// element range [x*per_xcd, (x+1)*per_xcd) (one eighth of the pages per L2/TLB).  Which
+// one is faster depends on the kernel: the chunked mapping is 0-4 % slower on round 1's
+// one-workgroup-per-CU all-streaming shapes (profiles/r01/kbench_xcd_mapping.log) and
+// 0.7-1.3 % FASTER on the two-workgroup defaults with the cache window
+// (profiles/r02/kbench_np4_nlev72_final.log), so every variant carries its measured
+// preference (KernelVariant::prefers_xcd_chunked; the three headline kernels: chunked)
+// and caar_set_xcd_chunked overrides it.  Speed only — any placement computes the
 // same thing.  Returns -1 for the padding blocks of the rounded-up grid.
 __device__ __forceinline__ long long element_of_block(const KernelArgs& k, unsigned b) {
   if (k.per_xcd == 0) return (long long)k.nets + b;
@@ -108,6 +112,30 @@ __device__ __forceinline__ lds_cptr lds_reread_ptr(const double* generic_ptr_int
   asm volatile("" : "+v"(a));
   return (lds_cptr)(size_t)a;
 }
+
+// -DCAAR_DEBUG builds (libcaar_hip_debug.so): the reference's only hot-path assertion, check_dp3d
+// (level_vectorized_ppscan/CaarFunctor.hpp:82-97: dp3d(np1) > 0 under !NDEBUG), as a device-side counter instead of an
+// abort — a trapping kernel takes the GPU down for everybody on this pool.  Every dp3d(np1) a kernel stores is checked;
+// caar_debug_dp3d_violations() (include/caar.h) returns how many were not positive.  (One counter per translation
+// unit: the library is built without relocatable device code.)
+#ifdef CAAR_DEBUG
+static __device__ unsigned long long g_debug_nonpositive_dp3d = 0;
+__device__ __forceinline__ void debug_check_dp3d(double dp_np1) {
+  if (!(dp_np1 > 0.0)) atomicAdd(&g_debug_nonpositive_dp3d, 1ULL);
+}
+// host side of this translation unit: read (and optionally clear) the counter
+static inline long long debug_dp3d_count_of_this_tu(int reset) {
+  unsigned long long n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_debug_nonpositive_dp3d), sizeof(n)) != hipSuccess) return -1;
+  if (reset) {
+    const unsigned long long zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_debug_nonpositive_dp3d), &zero, sizeof(zero));
+  }
+  return (long long)n;
+}
+#else
+__device__ __forceinline__ void debug_check_dp3d(double) {}
+#endif
 
 // One compiled kernel configuration for a given (np, nlev).
 struct KernelVariant {

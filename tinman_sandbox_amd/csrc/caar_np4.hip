@@ -95,14 +95,6 @@ KernelVariant kNp4Nlev72[] = {
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, false, false, 8, 0>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, true, false, 8, 0>", "9 waves x 2 tiles, nt; eta_dot_dpdn stored only where its bits change (skips the no-op write-back: NOT the contract traffic)", launch_np4<72, 2, 1, true, 1, 0, true, 3, 2, 0>},
     {"caar_np4_kernel<72, 3, 2, true, 1, 1, true, false, false, 8, 0>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt", launch_np4<72, 3, 2, true, 1, 1>},
-    {"caar_np4_kernel<72, 3, 2, true, 1, 0, true, false, false, 8, 0>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt, update loads one tile ahead", launch_np4<72, 3, 2, true, 0, 1>},
-    {"caar_np4_kernel<72, 2, 1, true, 1, 0, false, false, false, 8, 0>", "9 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<72, 2, 1, true, 0>},
-    {"caar_np4_kernel<72, 2, 1, true, 0, 1, false, false, false, 8, 0>", "9 waves x 2 tiles, default cache policy", launch_np4<72, 2, 1, false, 1>},
-    {"caar_np4_kernel<72, 3, 2, true, 1, 1, false, false, false, 8, 0>", "6 waves x 3 tiles, nt, update loads before the last barrier", launch_np4<72, 3, 2, true, 1>},
-    {"caar_np4_kernel<72, 3, 2, true, 2, 1, false, false, false, 8, 0>", "6 waves x 3 tiles, hybrid cache policy, update loads before the last barrier", launch_np4<72, 3, 2, 2, 1>},
-    {"caar_np4_kernel<72, 3, 2, true, 2, 0, false, false, false, 8, 0>", "6 waves x 3 tiles, room for 2 waves/SIMD, hybrid cache policy, update loads one tile ahead", launch_np4<72, 3, 2, 2, 0>},
-    {"caar_np4_kernel<72, 2, 1, true, 2, 0, false, false, false, 8, 0>", "9 waves x 2 tiles, hybrid cache policy, update loads one tile ahead", launch_np4<72, 2, 1, 2, 0>},
-    {"caar_np4_kernel<72, 6, 1, true, 2, 0, false, false, false, 8, 31>", "3 waves x 6 tiles, scan results parked in LDS, hybrid cache policy", launch_np4<72, 6, 1, 2, 0, 0, false, 3, 2, 0, 31>},
     {"caar_np4_kernel<72, 6, 1, true, 0, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU), default cache policy (nothing streams: what a fused multi-step launch wants)", launch_np4<72, 6, 1, 0, 0, 0, false, 6, 2, 0, 0, 43>, true, launch_np4_steps_72_0},
 };
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
@@ -112,12 +104,6 @@ KernelVariant kNp4Nlev128[] = {
     {"caar_np4_kernel<128, 8, 2, true, 1, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS, nt (all streaming), update loads one tile ahead", launch_np4<128, 8, 2, true, 0, 0, false, 4, 2, 0, 27, 32>, false, launch_np4_steps_128_1},
     {"caar_np4_kernel<128, 4, 2, true, 2, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<128, 4, 2, 2, 1, 0, false, 8, 1, 0>},
     {"caar_np4_kernel<128, 4, 2, true, 1, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 1, 0>},
-    {"caar_np4_kernel<128, 4, 2, true, 1, 0, false, false, false, 8, 0>", "8 waves x 4 tiles, nt, update loads one tile ahead", launch_np4<128, 4, 2, true, 0>},
-    {"caar_np4_kernel<128, 4, 2, true, 0, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, default cache policy", launch_np4<128, 4, 2, false, 1>},
-    {"caar_np4_kernel<128, 8, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 8 tiles, nt", launch_np4<128, 8, 1, true, 0>},
-    {"caar_np4_kernel<128, 2, 4, true, 1, 0, false, false, false, 8, 0>", "16 waves x 2 tiles, nt, update loads one tile ahead", launch_np4<128, 2, 4, true, 0, 0, false, 8, 1, 0>},
-    {"caar_np4_kernel<128, 4, 2, true, 2, 0, false, false, false, 8, 0>", "8 waves x 4 tiles, hybrid cache policy, update loads one tile ahead", launch_np4<128, 4, 2, 2, 0>},
-    {"caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8, 15>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / hydrostatic suffix / divdp parked in LDS, hybrid cache policy", launch_np4<128, 8, 2, 2, 0, 0, false, 8, 1, 0, 15>},
     {"caar_np4_kernel<128, 8, 2, true, 0, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), scan results parked in LDS, default cache policy (what a fused multi-step launch wants)", launch_np4<128, 8, 2, 0, 0, 0, false, 4, 2, 0, 27, 32>, true, launch_np4_steps_128_0},
 };
 int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
@@ -127,44 +113,26 @@ int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 KernelVariant kNp4Nlev32[] = {
     {"caar_np4_kernel<32, 2, 1, true, 2, 1, false, false, false, 8, 0>", "4 waves x 2 tiles, room for 1 wave/SIMD, hybrid cache policy", launch_np4<32, 2, 1, 2, 1>},
     {"caar_np4_kernel<32, 2, 1, true, 1, 1, false, false, false, 8, 0>", "4 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<32, 2, 1, true, 1>},
-    {"caar_np4_kernel<32, 1, 2, true, 1, 1, false, false, false, 8, 0>", "8 waves x 1 tile, room for 2 waves/SIMD, nt", launch_np4<32, 1, 2, true, 1>},
-    {"caar_np4_kernel<32, 2, 2, true, 1, 1, false, false, false, 8, 0>", "4 waves x 2 tiles, room for 2 waves/SIMD, nt", launch_np4<32, 2, 2, true, 1>},
-    {"caar_np4_kernel<32, 1, 4, true, 1, 1, false, false, false, 8, 0>", "8 waves x 1 tile, room for 4 waves/SIMD, nt", launch_np4<32, 1, 4, true, 1>},
-    {"caar_np4_kernel<32, 4, 1, true, 1, 1, false, false, false, 8, 0>", "2 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<32, 4, 1, true, 1>},
 };
 int kNp4Nlev32Count = sizeof(kNp4Nlev32) / sizeof(kNp4Nlev32[0]);
 KernelVariant kNp4Nlev60[] = {
     {"caar_np4_kernel<60, 1, 1, true, 2, 1, false, false, false, 8, 0>", "15 waves x 1 tile, room for 1 wave/SIMD, hybrid cache policy", launch_np4<60, 1, 1, 2, 1>},
     {"caar_np4_kernel<60, 1, 1, true, 1, 1, false, false, false, 8, 0>", "15 waves x 1 tile, room for 1 wave/SIMD, nt", launch_np4<60, 1, 1, true, 1>},
-    {"caar_np4_kernel<60, 3, 1, true, 1, 1, false, false, false, 8, 0>", "5 waves x 3 tiles, room for 1 wave/SIMD, nt", launch_np4<60, 3, 1, true, 1>},
-    {"caar_np4_kernel<60, 3, 2, true, 1, 1, false, false, false, 8, 0>", "5 waves x 3 tiles, room for 2 waves/SIMD, nt", launch_np4<60, 3, 2, true, 1>},
-    {"caar_np4_kernel<60, 5, 1, true, 1, 1, false, false, false, 8, 0>", "3 waves x 5 tiles, room for 1 wave/SIMD, nt", launch_np4<60, 5, 1, true, 1>},
 };
 int kNp4Nlev60Count = sizeof(kNp4Nlev60) / sizeof(kNp4Nlev60[0]);
 KernelVariant kNp4Nlev64[] = {
     {"caar_np4_kernel<64, 4, 2, true, 2, 1, false, false, false, 8, 0>", "4 waves x 4 tiles, room for 2 waves/SIMD, hybrid cache policy", launch_np4<64, 4, 2, 2, 1>},
     {"caar_np4_kernel<64, 4, 2, true, 1, 1, false, false, false, 8, 0>", "4 waves x 4 tiles, room for 2 waves/SIMD, nt", launch_np4<64, 4, 2, true, 1>},
-    {"caar_np4_kernel<64, 2, 1, true, 1, 1, false, false, false, 8, 0>", "8 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<64, 2, 1, true, 1>},
-    {"caar_np4_kernel<64, 2, 3, true, 1, 1, false, false, false, 8, 0>", "8 waves x 2 tiles, room for 3 waves/SIMD, nt", launch_np4<64, 2, 3, true, 1>},
-    {"caar_np4_kernel<64, 4, 1, true, 1, 1, false, false, false, 8, 0>", "4 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<64, 4, 1, true, 1>},
-    {"caar_np4_kernel<64, 1, 1, true, 1, 1, false, false, false, 8, 0>", "16 waves x 1 tile, room for 1 wave/SIMD, nt", launch_np4<64, 1, 1, true, 1>},
 };
 int kNp4Nlev64Count = sizeof(kNp4Nlev64) / sizeof(kNp4Nlev64[0]);
 KernelVariant kNp4Nlev80[] = {
     {"caar_np4_kernel<80, 2, 1, true, 2, 1, false, false, false, 8, 0>", "10 waves x 2 tiles, room for 1 wave/SIMD, hybrid cache policy", launch_np4<80, 2, 1, 2, 1, 0, false, 4, 2, 0>},
     {"caar_np4_kernel<80, 2, 1, true, 1, 1, false, false, false, 8, 0>", "10 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<80, 2, 1, true, 1, 0, false, 4, 2, 0>},
-    {"caar_np4_kernel<80, 4, 2, true, 1, 1, false, false, false, 8, 0>", "5 waves x 4 tiles, room for 2 waves/SIMD, nt", launch_np4<80, 4, 2, true, 1, 0, false, 4, 2, 0>},
-    {"caar_np4_kernel<80, 5, 1, true, 1, 1, false, false, false, 8, 0>", "4 waves x 5 tiles, room for 1 wave/SIMD, nt", launch_np4<80, 5, 1, true, 1, 0, false, 4, 2, 0>},
-    {"caar_np4_kernel<80, 4, 1, true, 1, 1, false, false, false, 8, 0>", "5 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<80, 4, 1, true, 1, 0, false, 4, 2, 0>},
 };
 int kNp4Nlev80Count = sizeof(kNp4Nlev80) / sizeof(kNp4Nlev80[0]);
 KernelVariant kNp4Nlev96[] = {
     {"caar_np4_kernel<96, 2, 1, true, 2, 1, false, false, false, 8, 0>", "12 waves x 2 tiles, room for 1 wave/SIMD, hybrid cache policy", launch_np4<96, 2, 1, 2, 1>},
     {"caar_np4_kernel<96, 2, 1, true, 1, 1, false, false, false, 8, 0>", "12 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<96, 2, 1, true, 1>},
-    {"caar_np4_kernel<96, 3, 1, true, 1, 1, false, false, false, 8, 0>", "8 waves x 3 tiles, room for 1 wave/SIMD, nt", launch_np4<96, 3, 1, true, 1>},
-    {"caar_np4_kernel<96, 4, 2, true, 1, 1, false, false, false, 8, 0>", "6 waves x 4 tiles, room for 2 waves/SIMD, nt", launch_np4<96, 4, 2, true, 1>},
-    {"caar_np4_kernel<96, 6, 1, true, 1, 1, false, false, false, 8, 0>", "4 waves x 6 tiles, room for 1 wave/SIMD, nt", launch_np4<96, 6, 1, true, 1>},
-    {"caar_np4_kernel<96, 3, 2, true, 1, 1, false, false, false, 8, 0>", "8 waves x 3 tiles, room for 2 waves/SIMD, nt", launch_np4<96, 3, 2, true, 1>},
 };
 int kNp4Nlev96Count = sizeof(kNp4Nlev96) / sizeof(kNp4Nlev96[0]);
 // Any other level count up to 256: the kernel with a run-time level count (NLEV_T = 0).
@@ -195,19 +163,16 @@ KernelVariant kNp4NlevAny[] = {{"caar_np4_kernel<0, ...>", "run-time level count
 KernelVariant kNp4Nlev26[] = {
     {"caar_np4_kernel<26, 7, 1, true, 2, 1, false, false, false, 8, 0>", "1 waves x 7 tiles, room for 1 wave/SIMD, hybrid cache policy", launch_np4<26, 7, 1, 2, 1>},
     {"caar_np4_kernel<26, 7, 1, true, 1, 1, false, false, false, 8, 0>", "1 waves x 7 tiles, room for 1 wave/SIMD, nt", launch_np4<26, 7, 1, true, 1>},
-    {"caar_np4_kernel<26, 1, 1, true, 1, 1, false, false, false, 8, 0>", "7 waves x 1 tile, room for 1 wave/SIMD, nt", launch_np4<26, 1, 1, true, 1>},
-    {"caar_np4_kernel<26, 1, 3, true, 1, 1, false, false, false, 8, 0>", "7 waves x 1 tile, room for 3 waves/SIMD, nt", launch_np4<26, 1, 3, true, 1>},
-    {"caar_np4_kernel<26, 1, 4, true, 1, 1, false, false, false, 8, 0>", "7 waves x 1 tile, room for 4 waves/SIMD, nt", launch_np4<26, 1, 4, true, 1>},
 };
 int kNp4Nlev26Count = sizeof(kNp4Nlev26) / sizeof(kNp4Nlev26[0]);
 KernelVariant kNp4Nlev30[] = {
     {"caar_np4_kernel<30, 2, 2, true, 2, 1, false, false, false, 8, 0>", "4 waves x 2 tiles, room for 2 waves/SIMD, hybrid cache policy", launch_np4<30, 2, 2, 2, 1>},
     {"caar_np4_kernel<30, 2, 2, true, 1, 1, false, false, false, 8, 0>", "4 waves x 2 tiles, room for 2 waves/SIMD, nt", launch_np4<30, 2, 2, true, 1>},
-    {"caar_np4_kernel<30, 2, 1, true, 1, 1, false, false, false, 8, 0>", "4 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<30, 2, 1, true, 1>},
-    {"caar_np4_kernel<30, 1, 2, true, 1, 1, false, false, false, 8, 0>", "8 waves x 1 tile, room for 2 waves/SIMD, nt", launch_np4<30, 1, 2, true, 1>},
-    {"caar_np4_kernel<30, 1, 4, true, 1, 1, false, false, false, 8, 0>", "8 waves x 1 tile, room for 4 waves/SIMD, nt", launch_np4<30, 1, 4, true, 1>},
-    {"caar_np4_kernel<30, 4, 1, true, 1, 1, false, false, false, 8, 0>", "2 waves x 4 tiles, room for 1 wave/SIMD, nt", launch_np4<30, 4, 1, true, 1>},
 };
 int kNp4Nlev30Count = sizeof(kNp4Nlev30) / sizeof(kNp4Nlev30[0]);
+
+#ifdef CAAR_DEBUG
+long long debug_dp3d_count_np4(int reset) { return debug_dp3d_count_of_this_tu(reset); }
+#endif
 
 }  // namespace caar

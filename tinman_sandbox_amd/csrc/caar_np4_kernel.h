@@ -460,8 +460,10 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);              // P:252
       stream_store<SNT>(v_np1 + off, vo);
       stream_store<SNT>(T_np1 + off, spheremp * (cur.Tnm1 + k.dt2 * ttens));        // P:253
-      if (VADV) stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * (divdp_r + eta_hi - eta_lo)));  // X:515-517
-      else stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * divdp_r));   // P:254
+      const double dp_new = VADV ? spheremp * (cur.dpnm1 - k.dt2 * (divdp_r + eta_hi - eta_lo))   // X:515-517
+                                 : spheremp * (cur.dpnm1 - k.dt2 * divdp_r);                       // P:254
+      debug_check_dp3d(dp_new);  // CaarFunctor.hpp:82-97 check_dp3d (-DCAAR_DEBUG builds only)
+      stream_store<SNT>(dp_np1 + off, dp_new);
       stream_store<SNT>(phi_out + off, phi);                                        // P:294,303,309
       stream_store<ANT>(omega_p + off, cur.om + k.eta_ave_w * om);                  // P:173
       dbl2 vn;

@@ -98,4 +98,8 @@ hipError_t launch_np4_steps_128_auto(const KernelArgs& k, int num_elems, int nst
   return num_elems >= 3700 ? launch_np4_steps_128_0(k, num_elems, nsteps, rotate, s) : launch_np4_steps_128_2(k, num_elems, nsteps, rotate, s);
 }
 
+#ifdef CAAR_DEBUG
+long long debug_dp3d_count_np4_steps(int reset) { return debug_dp3d_count_of_this_tu(reset); }
+#endif
+
 }  // namespace caar

@@ -3,19 +3,19 @@
 // Same algorithm and reference citations as caar_np4.hip (P = cxx/pointers_only/
 // compute_and_apply_rhs.cpp, S = sphere_operators.cpp); different mapping because one
 // level of an NP=8 element is exactly one wavefront:
-//   * one workgroup = one element; lane = GLL point a*8+b; a wave owns TPW consecutive
+//   * one workgroup = one element; lane -> GLL point by the MFMA result layout (np8::mfma_point; a*8+b in the
+//     LDS-tile comparator variant); a wave owns TPW consecutive
 //     levels and walks them in registers, so the three vertical integrals are plain
 //     running sums inside a wave (the reference's own summation order within the
 //     chunk) plus one wave total per integral exchanged through LDS (two barriers).
 //   * every field access of a wave is one contiguous 512 B (scalar) / 1 KiB (v) row of
 //     the reference layout [lev][a][b]: each byte read once, written once.
-//   * the 8x8 Dvv contractions go through a wave-private 512 B LDS tile: the field is
-//     written once and each lane reads its row (4 x ds_read_b128) or column
-//     (8 x ds_read_b64); Dvv is staged transposed in LDS so that both coefficient
-//     vectors are contiguous.  That is the direct form (variants 2..); the DEFAULT form (MFMA = true)
-//     runs the contractions on v_mfma_f64_4x4x4 with the lane -> point mapping of the MFMA result
-//     layout and no LDS tile at all (caar_np8_ops.h "MFMA form"): measured 1 % faster A/B
-//     (profiles/r02/kbench_np8_nlev72_mfma.log).
+//   * the 8x8 Dvv contractions run on the matrix cores (DEFAULT, MFMA = true): v_mfma_f64_4x4x4, two issues per
+//     8x8 product, operands placed by one bank-masked DPP row_ror (d/da) or one ds_bpermute (d/db) per k-block,
+//     results landing where the pointwise code needs them — no LDS tile, no LDS copy of Dvv (caar_np8_ops.h "MFMA
+//     form"; +1 % A/B against the direct form, profiles/r02/kbench_np8_nlev72_mfma.log).  The direct form (one
+//     comparator variant): a wave-private 512 B LDS tile, the field written once and each lane reading its row
+//     (4 x ds_read_b128) or column (8 x ds_read_b64), Dvv staged transposed in LDS.
 //   * an NP=8 element does not fit the register file the way an NP=4 one does (7 live
 //     values x 64 points x 72 levels = 258 KB): between the phases dp, u, v, T of every
 //     level are read through a two-deep prefetch ring, dp, u, v are parked in LDS
@@ -345,8 +345,10 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);                   // P:252
     stream_store<SNT>(v_np1 + off, vo);
     stream_store<SNT>(T_np1 + off, spheremp * (cur.Tnm1 + k.dt2 * ttens));       // P:253
-    if (VADV) stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * (divdp[r] + eta_hi - eta_lo)));  // X:515-517
-    else stream_store<SNT>(dp_np1 + off, spheremp * (cur.dpnm1 - k.dt2 * divdp[r]));  // P:254
+    const double dp_new = VADV ? spheremp * (cur.dpnm1 - k.dt2 * (divdp[r] + eta_hi - eta_lo))  // X:515-517
+                               : spheremp * (cur.dpnm1 - k.dt2 * divdp[r]);                     // P:254
+    debug_check_dp3d(dp_new);  // CaarFunctor.hpp:82-97 check_dp3d (-DCAAR_DEBUG builds only)
+    stream_store<SNT>(dp_np1 + off, dp_new);
     stream_store<SNT>(phi_out + off, phi);
     stream_store<SNT>(omega_p + off, cur.om + k.eta_ave_w * om);                 // P:173
     dbl2 vn;
@@ -382,16 +384,13 @@ KernelVariant kNp8Nlev72[] = {
     {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, true, 2>", "8 waves x 9 levels, nt, MFMA contractions, update-phase inputs requested two levels ahead", launch_np8<72, 9, 1, true, false, false, false, true, 2>, true},
     {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, true, 1>", "8 waves x 9 levels, nt, Dvv contractions on v_mfma_f64_4x4x4 (lane = MFMA result layout, no LDS tile)", launch_np8<72, 9, 1, true, false, false, false, true>},
     {"caar_np8_kernel<72, 9, 1, true, true, true, false, false, false, false, 1>", "8 waves x 9 levels, nt, Dvv slices re-read from LDS", launch_np8<72, 9, 1, true, true, false, false>},
-    {"caar_np8_kernel<72, 9, 1, true, true, true, false, true, false, false, 1>", "8 waves x 9 levels, nt, Dvv slices from LDS, operators batched per level", launch_np8<72, 9, 1, true, true, false, true>},
-    {"caar_np8_kernel<72, 9, 1, true, true, true, true, true, false, false, 1>", "8 waves x 9 levels, nt, Dvv slices from LDS, T re-read, operators batched", launch_np8<72, 9, 1, true, true, true, true>},
-    {"caar_np8_kernel<72, 9, 1, true, true, true, true, false, false, false, 1>", "8 waves x 9 levels, nt, Dvv slices from LDS, T re-read in the last phase", launch_np8<72, 9, 1, true, true, true, false>},
-    {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, false, 1>", "8 waves x 9 levels, nt, Dvv slices in registers", launch_np8<72, 9, 1, true, false, false, false>},
     {"caar_np8_kernel<72, 9, 1, true, false, true, false, false, false, false, 1>", "8 waves x 9 levels, default cache policy", launch_np8<72, 9, 1, false, true, false, false>},
-    {"caar_np8_kernel<72, 18, 1, true, true, false, false, true, false, false, 1>", "4 waves x 18 levels (one wave per SIMD), nt, operators batched", launch_np8<72, 18, 1, true, false, false, true>},
-    {"caar_np8_kernel<72, 9, 1, true, true, false, true, false, false, true, 1>", "8 waves x 9 levels, nt, MFMA contractions, T re-read in the last phase", launch_np8<72, 9, 1, true, false, true, false, true>},
     {"caar_np8_kernel<72, 12, 1, true, true, false, false, false, false, true, 1>", "6 waves x 12 levels, nt, MFMA contractions", launch_np8<72, 12, 1, true, false, false, false, true>},
-    {"caar_np8_kernel<72, 9, 1, true, true, false, true, false, false, true, 2>", "8 waves x 9 levels, nt, MFMA contractions, T re-read, update-phase inputs two levels ahead", launch_np8<72, 9, 1, true, false, true, false, true, 2>},
 };
 int kNp8Nlev72Count = sizeof(kNp8Nlev72) / sizeof(kNp8Nlev72[0]);
+
+#ifdef CAAR_DEBUG
+long long debug_dp3d_count_np8(int reset) { return debug_dp3d_count_of_this_tu(reset); }
+#endif
 
 }  // namespace caar

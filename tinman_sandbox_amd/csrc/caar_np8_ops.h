@@ -1,5 +1,6 @@
-// caar_np8_ops.h — the three sphere operators for NP=8: one level = one wavefront, the
-// 8x8 Dvv contractions go through a wave-private 64-double LDS tile (see caar_np8.hip).
+// caar_np8_ops.h — the three sphere operators for NP=8: one level = one wavefront.  Two forms of the 8x8 Dvv
+// contractions: the DEFAULT "MFMA form" (v_mfma_f64_4x4x4, lane = MFMA result layout, no LDS tile; further down) and
+// the direct form through a wave-private 64-double LDS tile (the comparator variant; first in this file).
 // Reference: cxx/pointers_only/sphere_operators.cpp:9-129 (S:).
 #ifndef CAAR_NP8_OPS_H
 #define CAAR_NP8_OPS_H

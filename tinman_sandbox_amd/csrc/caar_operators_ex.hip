@@ -191,20 +191,46 @@ __global__ __launch_bounds__(256) void sphere_operator_ex_kernel(const OpArgs a)
         s2c[k][1] = t.y;
       }
     }
+    // PREFETCH: the input of the wave's NEXT tile is requested before the current one is computed.  Worth +1..4 % on the
+    // simple operators (one contraction pair per point: memory-bound).  The composites at NP=4 (laplace_*: 2 pairs,
+    // vlaplace_*: 4-6 pairs per point for 1-2 KiB of traffic per tile) are bound by VALU issue, not by memory — 14 DPP
+    // moves + 8 FMAs per pair put their ceiling at ~5.6 TB/s — and lose 8-10 % to the extra live registers and
+    // instructions, so they load in place (profiles/r03/operator_bench_large.log: with / without).
+    constexpr bool COMPOSITE = WHICH == OP_LAP || WHICH == OP_LAP_T || WHICH == OP_LAP_T_REPL || WHICH == OP_VLAP_CONTRA ||
+                               WHICH == OP_VLAP_CART || WHICH == OP_VLAP_CART_DAMPED;
+    constexpr bool PREFETCH = !(NP == 4 && COMPOSITE);
+    auto load_in = [&](int st_, double& s_, V2& v_, V2& old_) {
+      const int lev_ = st_ * LPT + sub;
+      s_ = 0;
+      v_ = {0, 0};
+      old_ = {0, 0};
+      if (st_ < nsteps && lev_ < a.nlevels) {
+        const size_t o_ = ((size_t)e * a.nlevels + lev_) * PP + pt;
+        if (WHICH == OP_GRAD_UPD) {  // the accumulated-into values of the update forms travel with the input
+          const dbl2 t = *(reinterpret_cast<const dbl2*>(a.out) + o_);
+          old_ = {t.x, t.y};
+        } else if (WHICH == OP_DIV_UPD) {
+          old_.x = a.out[o_];
+        }
+        if (op_vector_in(WHICH)) {
+          const dbl2 t = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(a.in) + o_);
+          v_ = {t.x, t.y};
+        } else {
+          s_ = __builtin_nontemporal_load((IN_PLACE ? a.out : a.in) + o_);
+        }
+      }
+    };
+    double s_next = 0;
+    V2 v_next = {0, 0}, old_next = {0, 0};
+    if (PREFETCH) load_in(w, s_next, v_next, old_next);
     for (int st = w; st < nsteps; st += nw) {  // wave-uniform trip count; every lane runs the cross-lane code
       const int lev = st * LPT + sub;
       const bool live = lev < a.nlevels;
       const size_t o = ((size_t)e * a.nlevels + lev) * PP + pt;
-      double s = 0;
-      V2 v = {0, 0};
-      if (live) {
-        if (op_vector_in(WHICH)) {
-          const dbl2 t = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(a.in) + o);
-          v = {t.x, t.y};
-        } else {
-          s = __builtin_nontemporal_load((IN_PLACE ? a.out : a.in) + o);
-        }
-      }
+      if (!PREFETCH) load_in(st, s_next, v_next, old_next);
+      const double s = s_next;
+      const V2 v = v_next, old = old_next;
+      if (PREFETCH) load_in(st + nw, s_next, v_next, old_next);
       double rs = 0;
       V2 rv = {0, 0};
       if constexpr (WHICH == OP_GRAD || WHICH == OP_GRAD_UPD) rv = op_gradient(x, Dinv, rr, s);
@@ -235,15 +261,12 @@ __global__ __launch_bounds__(256) void sphere_operator_ex_kernel(const OpArgs a)
       if (op_vector_out(WHICH)) {
         dbl2* po = reinterpret_cast<dbl2*>(a.out) + o;
         dbl2 t = {rv.x, rv.y};
-        if (WHICH == OP_GRAD_UPD) {  // K:303-308: grad_s += ...
-          const dbl2 old = *po;
-          t = {old.x + rv.x, old.y + rv.y};
-        }
+        if (WHICH == OP_GRAD_UPD) t = {old.x + rv.x, old.y + rv.y};  // K:303-308: grad_s += ...
         __builtin_nontemporal_store(t, po);
       } else {
         double t = rs;
         if (WHICH == OP_DIV_UPD) {  // K:398-399: div_v *= beta; div_v += alpha * (...)
-          t = a.out[o] * a.beta;
+          t = old.x * a.beta;
           t += a.alpha * rs;
         }
         __builtin_nontemporal_store(t, a.out + o);

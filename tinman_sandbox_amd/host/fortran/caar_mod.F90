@@ -52,6 +52,9 @@ module caar_mod
     integer(c_int) function caar_upload_f90(ctx, f90_host, e0, e1) bind(C, name="caar_upload_f90")
       import; type(c_ptr), value :: ctx; type(caar_arrays_t) :: f90_host; integer(c_int), value :: e0, e1
     end function
+    integer(c_int) function caar_upload_f90_arrays(ctx, f90_host, e0, e1, array_mask) bind(C, name="caar_upload_f90_arrays")
+      import; type(c_ptr), value :: ctx; type(caar_arrays_t) :: f90_host; integer(c_int), value :: e0, e1, array_mask
+    end function
     integer(c_int) function caar_download_f90(ctx, f90_host, e0, e1, all_arrays) bind(C, name="caar_download_f90")
       import; type(c_ptr), value :: ctx; type(caar_arrays_t) :: f90_host; integer(c_int), value :: e0, e1, all_arrays
     end function

@@ -10,10 +10,14 @@
 !
 ! The reference keeps its fields inside the derived type, elem(ie)%state%v(np,np,2,nlev,timelevels) etc.
 ! (element_state_mod.F90:17-23, element_mod.F90:63-121): one struct per element, so the fields of different elements
-! are not contiguous.  Every call therefore gathers the sixteen arrays of elements nets..nete into flat
-! Fortran-ordered arrays (the layout caar_upload_f90 takes), runs, and scatters back what the path mutates:
-! state%v/T/dp3d at np1, derived%vn0/omega_p/eta_dot_dpdn/phi.  Host semantics are the reference's; a host that steps
-! in a loop and wants the data to stay on the GPU uses caar_mod directly (caar_f90_driver.F90).
+! are not contiguous.  Every call therefore gathers the arrays of elements nets..nete into flat Fortran-ordered
+! arrays (the layout caar_upload_f90 takes), runs, and scatters back what the path mutates: state%v/T/dp3d at np1,
+! derived%vn0/omega_p/eta_dot_dpdn/phi.  What crosses PCIe per call is what can have changed: the fields the path reads
+! and the host may have touched (state dp3d/T/v, Qdp only in the moist branch, the three accumulators); the constant
+! inputs (D, Dinv, fcor, spheremp, metdet, rmetdet, phis, pecnd) are compared with the staged copy and uploaded only
+! when they differ (i.e. on the first call); derived%phi is output only and never goes up.  Host semantics are the
+! reference's; a host that steps in a loop and wants the data to stay on the GPU uses caar_mod directly
+! (caar_f90_driver.F90).  caar_routine_finalize() releases the device context and the staging arrays.
 ! Called from one thread at a time, as the reference's main.F90 does (its OpenMP is inside the routine, over levels:
 ! routine_mod.F90:76-137); the device context and the staging arrays are module state, created on first use.
 module routine_mod
@@ -21,10 +25,11 @@ module routine_mod
   use caar_mod
   implicit none
   private
-  public :: compute_and_apply_rhs
+  public :: compute_and_apply_rhs, caar_routine_finalize
 
   type(c_ptr), save :: ctx = c_null_ptr
   integer, save :: ctx_elems = 0
+  logical, allocatable, save :: const_valid(:)   ! element ie's constant inputs are on the device
   real(c_double), allocatable, target, save :: gD(:,:,:,:,:), gDinv(:,:,:,:,:)
   real(c_double), allocatable, target, save :: gfcor(:,:,:), gspheremp(:,:,:), gmetdet(:,:,:), grmetdet(:,:,:), gphis(:,:,:)
   real(c_double), allocatable, target, save :: gdp3d(:,:,:,:,:), gT(:,:,:,:,:), gv(:,:,:,:,:,:), gQdp(:,:,:,:,:,:)
@@ -50,12 +55,29 @@ contains
     type(caar_arrays_t) :: a
     type(caar_params_t) :: prm
     integer :: ie, ne, i, j
+    integer(c_int) :: mask
+    ! CaarArrays member order (include/caar.h): bit i = array i
+    integer(c_int), parameter :: M_CONST = int(b'0100001000111111', c_int)  ! D Dinv fcor spheremp metdet rmetdet phis pecnd
+    integer(c_int), parameter :: M_STATE = int(b'1001100111000000', c_int)  ! dp3d v T eta_dot_dpdn omega_p vn0
+    integer(c_int), parameter :: M_QDP = int(b'0000010000000000', c_int)
 
     ne = size(elem)
     if (ne /= ctx_elems) call resize(ne, np, nlev, timelevels, qsize_d)
 
     ! gather (first index fastest, element last: the layout of include/caar.h "Fortran-layout ingest / egress")
+    mask = M_STATE
+    if (qn0 >= 1) mask = ior(mask, M_QDP)
     do ie = nets, nete
+      ! constant inputs: staged and uploaded only when they differ from what the device already has
+      if (.not. const_valid(ie)) then
+        mask = ior(mask, M_CONST)
+      else if (any(gD(:,:,:,:,ie) /= elem(ie)%D) .or. any(gDinv(:,:,:,:,ie) /= elem(ie)%Dinv) .or. &
+               any(gfcor(:,:,ie) /= elem(ie)%fcor) .or. any(gspheremp(:,:,ie) /= elem(ie)%spheremp) .or. &
+               any(gmetdet(:,:,ie) /= elem(ie)%metdet) .or. any(grmetdet(:,:,ie) /= elem(ie)%rmetdet) .or. &
+               any(gphis(:,:,ie) /= elem(ie)%state%phis) .or. any(gpecnd(:,:,:,ie) /= elem(ie)%derived%pecnd)) then
+        mask = ior(mask, M_CONST)
+      end if
+      const_valid(ie) = .true.
       gD(:,:,:,:,ie) = elem(ie)%D
       gDinv(:,:,:,:,ie) = elem(ie)%Dinv
       gfcor(:,:,ie) = elem(ie)%fcor
@@ -70,7 +92,6 @@ contains
       if (qn0 >= 1) gQdp(:,:,:,:,1,ie) = elem(ie)%state%Qdp(:,:,:,:,qn0)
       geta(:,:,:,ie) = elem(ie)%derived%eta_dot_dpdn
       gomega(:,:,:,ie) = elem(ie)%derived%omega_p
-      gphi(:,:,:,ie) = elem(ie)%derived%phi
       gpecnd(:,:,:,ie) = elem(ie)%derived%pecnd
       gvn0(:,:,:,:,ie) = elem(ie)%derived%vn0
     end do
@@ -97,7 +118,7 @@ contains
     prm%ps0 = hvcoord%ps0; prm%hyai0 = hvcoord%hyai(1)
     prm%Dvv = c_loc(Dvv_c)
 
-    call caar_check(caar_upload_f90(ctx, a, int(nets - 1, c_int), int(nete, c_int)), 'caar_upload_f90')
+    call caar_check(caar_upload_f90_arrays(ctx, a, int(nets - 1, c_int), int(nete, c_int), mask), 'caar_upload_f90_arrays')
     call caar_check(caar_run(ctx, prm), 'caar_run')
     call caar_check(caar_download_f90(ctx, a, int(nets - 1, c_int), int(nete, c_int), 0_c_int), 'caar_download_f90')
     call caar_check(caar_sync(ctx), 'caar_sync')
@@ -122,10 +143,9 @@ contains
       print *, 'caar: no MI355X kernel for np, nlev = ', np, nlev
       error stop 1
     end if
-    if (c_associated(ctx)) then
-      call caar_destroy(ctx)
-      deallocate(gD, gDinv, gfcor, gspheremp, gmetdet, grmetdet, gphis, gdp3d, gT, gv, gQdp, geta, gomega, gphi, gpecnd, gvn0)
-    end if
+    call caar_routine_finalize()
+    allocate(const_valid(ne))
+    const_valid = .false.
     allocate(gD(np,np,2,2,ne), gDinv(np,np,2,2,ne))
     allocate(gfcor(np,np,ne), gspheremp(np,np,ne), gmetdet(np,np,ne), grmetdet(np,np,ne), gphis(np,np,ne))
     allocate(gdp3d(np,np,nlev,timelevels,ne), gT(np,np,nlev,timelevels,ne), gv(np,np,2,nlev,timelevels,ne))
@@ -136,5 +156,17 @@ contains
     call caar_check(caar_create(ctx, dims, 0_c_int), 'caar_create')
     ctx_elems = ne
   end subroutine resize
+
+  ! Releases the device context and the staging arrays (the reference's routine holds no state, so it has no such
+  ! call; a host that links this module calls it before it ends, or never — the process exit releases everything).
+  subroutine caar_routine_finalize()
+    if (c_associated(ctx)) then
+      call caar_destroy(ctx)
+      ctx = c_null_ptr
+      deallocate(gD, gDinv, gfcor, gspheremp, gmetdet, grmetdet, gphis, gdp3d, gT, gv, gQdp, geta, gomega, gphi, gpecnd, gvn0)
+      deallocate(const_valid)
+    end if
+    ctx_elems = 0
+  end subroutine caar_routine_finalize
 
 end module routine_mod
