@@ -93,5 +93,43 @@ __device__ __forceinline__ RowCoef make_row_coef(const double* dvv, int lane) {
   return c;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// MFMA form of the NP=4 contractions, for kernels that are bound by VALU issue rather than by memory (the composite
+// operators of caar_operators_ex.hip: 2-6 contraction pairs per point for 1-2 KiB of traffic per tile; the DPP form
+// costs 14 cross-lane moves + 8 FMAs per pair).  v_mfma_f64_4x4x4_4b_f64 multiplies four independent 4x4 blocks per
+// issue: one block = one LEVEL of the tile, so one issue is one contraction of all four levels a wave holds.
+// Operand layouts (measured: tools/probes/mfma_f64_probe.hip, profiles/r02/mfma_probe.log):
+//     A[blk][i][k] in lane 16k + 4blk + i,   B[blk][k][j] in lane 16k + 4blk + j,   D[blk][i][j] in lane 16i + 4blk + j.
+// A kernel that uses these adopts lane = 16a + 4lev + b as its lane -> (GLL point, level) mapping (mfma4_point /
+// mfma4_level; the wave still covers the same 64 consecutive doubles of the layout [lev][a][b]): a field F in that
+// mapping IS a B operand and a result, so
+//   da(F) = Dvv^T . F : A = Dvv^T (a per-lane constant), B = F              -> one MFMA, no cross-lane move at all
+//   db(F) = F . Dvv   : A = F in the transposed in-block placement (one 64-bit ds_bpermute), B = Dvv (constant)
+//   wa, wb            : the same with the constants taken from Dvv^T.
+__device__ __forceinline__ int mfma4_point(int lane) { return (lane >> 4) * 4 + (lane & 3); }  // a*4 + b
+__device__ __forceinline__ int mfma4_level(int lane) { return (lane >> 2) & 3; }               // level inside the tile
+struct Mfma4Ctx {
+  double d_hl;  // Dvv[h][l] for lane = 16h + 4blk + l: A operand of da, B operand of db
+  double d_lh;  // Dvv[l][h]: A operand of wa, B operand of wb
+  int src_t;    // the lane that holds F[l][h] of this lane's level: 16l + 4blk + h
+};
+__device__ __forceinline__ Mfma4Ctx make_mfma4_ctx(const double* dvv /* Dvv[k][j] row-major */, int lane) {
+  const int h = lane >> 4, blk = (lane >> 2) & 3, l = lane & 3;
+  Mfma4Ctx c;
+  c.d_hl = dvv[h * 4 + l];
+  c.d_lh = dvv[l * 4 + h];
+  c.src_t = 16 * l + 4 * blk + h;
+  return c;
+}
+__device__ __forceinline__ double mfma4x4(double a, double b) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, 0.0, 0, 0, 0); }
+// sum_k Dvv[k][a] f[k][b]
+__device__ __forceinline__ double mfma4_d_da(const Mfma4Ctx& c, double f) { return mfma4x4(c.d_hl, f); }
+// sum_k Dvv[k][b] f[a][k]
+__device__ __forceinline__ double mfma4_d_db(const Mfma4Ctx& c, double f) { return mfma4x4(__shfl(f, c.src_t, 64), c.d_hl); }
+// sum_k Dvv[a][k] f[k][b]
+__device__ __forceinline__ double mfma4_w_a(const Mfma4Ctx& c, double f) { return mfma4x4(c.d_lh, f); }
+// sum_k Dvv[b][k] f[a][k]
+__device__ __forceinline__ double mfma4_w_b(const Mfma4Ctx& c, double f) { return mfma4x4(__shfl(f, c.src_t, 64), c.d_lh); }
+
 }  // namespace caar
 #endif

@@ -34,6 +34,13 @@ struct X4 {  // NP=4: lane = sub*16 + a*4 + b
   __device__ __forceinline__ double wa(double f) const { return d_da(ct, f); }
   __device__ __forceinline__ double wb(double f) const { return d_db(ct, f); }
 };
+struct X4M {  // NP=4 on the matrix cores: lane = 16a + 4lev + b (caar_np4_ops.h "MFMA form")
+  Mfma4Ctx c;
+  __device__ __forceinline__ double da(double f) const { return mfma4_d_da(c, f); }
+  __device__ __forceinline__ double db(double f) const { return mfma4_d_db(c, f); }
+  __device__ __forceinline__ double wa(double f) const { return mfma4_w_a(c, f); }
+  __device__ __forceinline__ double wb(double f) const { return mfma4_w_b(c, f); }
+};
 struct X8 {  // NP=8: lane = MFMA result layout (np8::mfma_point)
   np8::MfmaCtx c, ct;
   __device__ __forceinline__ double da(double f) const { return np8::mfma_d_da(c, f); }
@@ -142,9 +149,19 @@ __global__ __launch_bounds__(256) void sphere_operator_ex_kernel(const OpArgs a)
     s_dvvT[(i % NP) * NP + i / NP] = d;
   }
   __syncthreads();
-  typename std::conditional<NP == 4, X4, X8>::type x;
+  // The composites (laplace_*: 2 contraction pairs per point, vlaplace_*: 4-6, for 1-2 KiB of traffic per tile) are
+  // bound by VALU issue in the DPP form (14 cross-lane moves + 8 FMAs per pair: 4.1-4.9 TB/s at NP=4,
+  // profiles/r03/operator_bench_large.log); they run their contractions on the matrix cores instead.
+  constexpr bool COMPOSITE = WHICH == OP_LAP || WHICH == OP_LAP_T || WHICH == OP_LAP_T_REPL || WHICH == OP_VLAP_CONTRA ||
+                             WHICH == OP_VLAP_CART || WHICH == OP_VLAP_CART_DAMPED;
+  constexpr bool MF4 = NP == 4 && COMPOSITE;
+  typename std::conditional<NP == 4, typename std::conditional<MF4, X4M, X4>::type, X8>::type x;
   int pt, sub;
-  if constexpr (NP == 4) {
+  if constexpr (MF4) {
+    x.c = make_mfma4_ctx(s_dvv, lane);
+    pt = mfma4_point(lane);
+    sub = mfma4_level(lane);
+  } else if constexpr (NP == 4) {
     x.c = make_row_coef(s_dvv, lane);
     x.ct = make_row_coef(s_dvvT, lane);
     pt = lane & 15;
@@ -191,14 +208,9 @@ __global__ __launch_bounds__(256) void sphere_operator_ex_kernel(const OpArgs a)
         s2c[k][1] = t.y;
       }
     }
-    // PREFETCH: the input of the wave's NEXT tile is requested before the current one is computed.  Worth +1..4 % on the
-    // simple operators (one contraction pair per point: memory-bound).  The composites at NP=4 (laplace_*: 2 pairs,
-    // vlaplace_*: 4-6 pairs per point for 1-2 KiB of traffic per tile) are bound by VALU issue, not by memory — 14 DPP
-    // moves + 8 FMAs per pair put their ceiling at ~5.6 TB/s — and lose 8-10 % to the extra live registers and
-    // instructions, so they load in place (profiles/r03/operator_bench_large.log: with / without).
-    constexpr bool COMPOSITE = WHICH == OP_LAP || WHICH == OP_LAP_T || WHICH == OP_LAP_T_REPL || WHICH == OP_VLAP_CONTRA ||
-                               WHICH == OP_VLAP_CART || WHICH == OP_VLAP_CART_DAMPED;
-    constexpr bool PREFETCH = !(NP == 4 && COMPOSITE);
+    // PREFETCH: the input of the wave's NEXT tile is requested before the current one is computed (+1..4 % on the
+    // memory-bound operators; profiles/r03/operator_bench_large.log: with / without).
+    constexpr bool PREFETCH = true;
     auto load_in = [&](int st_, double& s_, V2& v_, V2& old_) {
       const int lev_ = st_ * LPT + sub;
       s_ = 0;
