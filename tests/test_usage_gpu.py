@@ -390,11 +390,12 @@ def test_arrays_placed_for_bandwidth_compute_the_same(oracle, monkeypatch):
     assert free1 - free2 < (64 << 20), (free1, free2)   # no physical memory lost per allocate / release cycle
 
 
-def test_released_address_ranges_are_reused_correctly(oracle):
-    """An arena's virtual range is given back on release (one hipMemUnmap per mapped chunk, then hipMemAddressFree); the
-    next arena may get the same addresses and must see ITS memory there.  Round 2 unmapped the whole range with one call,
-    which leaves all chunks but the first translated to released memory (tools/probes/vmm_va_reuse_probe.hip); this is
-    the sequence that failed then: arenas of different sizes allocated, run, checked and released in turn."""
+def test_arenas_allocated_and_released_in_turn_stay_correct(oracle):
+    """The sequence that gave wrong results in round 2 — arenas of different sizes allocated, run, checked and released in
+    turn.  On ROCm 7.2 / gfx950 a virtual address that is mapped a second time keeps translating to its first physical
+    memory (bare-HIP reproducer tools/probes/vmm_va_reuse_probe.hip, profiles/r03/vmm_va_reuse_probe.log), so the
+    allocator unmaps chunk by chunk, returns the physical memory and keeps a released arena's range reserved: no address is
+    ever mapped twice, and every new arena must see ITS memory."""
     import gc
     for rep in range(2):
         for np_, nlev, E, gold_name in ((4, 72, 6000, "np4_nlev72_closed"), (4, 128, 3000, "np4_nlev128_closed"),
