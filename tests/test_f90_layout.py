@@ -101,6 +101,39 @@ def test_fortran_host_roundtrip_matches_reference_fortran():
 
 
 @pytest.mark.gpu
+def test_context_upload_of_selected_fortran_arrays():
+    """caar_upload_f90_arrays: only the arrays of the mask go up (what the Fortran drop-in does with the constant
+    geometry: once), the others keep what the device holds; NULL pointers are allowed for arrays outside the mask."""
+    import ctypes as C
+    from tinman_sandbox_amd import caar as m
+    L = tsa.library()
+    arrs, Dvv, sc = cases.make_case("np4_nlev72_hashed")
+    ne = arrs["elem_fcor"].shape[0]
+    f90 = fl.to_f90_numpy(arrs)
+    other = {k: np.ascontiguousarray(v + 1.0) for k, v in f90.items()}
+    dims = m._CaarDims(4, 72, 1, 3, ne)
+    ctx = C.c_void_p()
+    L.check(L.lib.caar_create(C.byref(ctx), C.byref(dims), 0), "create")
+    try:
+        full = m._CaarArrays(*[f90[n].ctypes.data_as(m._dp) for n in m.ARRAY_NAMES])
+        L.check(L.lib.caar_upload_f90(ctx, C.byref(full), 0, ne), "upload all")
+        picked = ("elem_state_T", "elem_derived_vn0", "elem_D")
+        mask = sum(1 << m.ARRAY_NAMES.index(n) for n in picked)
+        part = m._CaarArrays(*[(other[n].ctypes.data_as(m._dp) if n in picked else None) for n in m.ARRAY_NAMES])
+        L.check(L.lib.caar_upload_f90_arrays(ctx, C.byref(part), 0, ne, mask), "upload some")
+        back = {n: np.zeros_like(f90[n]) for n in m.ARRAY_NAMES}
+        ptrs = m._CaarArrays(*[back[n].ctypes.data_as(m._dp) for n in m.ARRAY_NAMES])
+        L.check(L.lib.caar_download_f90(ctx, C.byref(ptrs), 0, ne, 1), "download")
+        L.check(L.lib.caar_sync(ctx), "sync")
+        for n in m.ARRAY_NAMES:
+            assert np.array_equal(back[n], other[n] if n in picked else f90[n]), n
+        # a masked-in array without a pointer is an error
+        assert L.lib.caar_upload_f90_arrays(ctx, C.byref(part), 0, ne, mask | 2) == -1
+    finally:
+        L.lib.caar_destroy(ctx)
+
+
+@pytest.mark.gpu
 def test_layout_kernels_full_size_roundtrip():
     """10 000 elements: egress then ingest is the identity (a permutation and its inverse)."""
     data = tsa.TestData().init_data(10000, 4, 72, device="cuda")

@@ -332,6 +332,33 @@ def test_euler_step_validates_its_arguments():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("np_", NPS)
+def test_hip_single_level_forms_match_oracle(oracle, np_):
+    """The reference's `_sl` forms (level_vectorized_ppscan/SphereOperators.hpp:17-227: gradient / divergence_wk /
+    vorticity ... of ONE level) are the batched entry point with nlevels = 1 (NP=4: one live row of a tile, three dead
+    ones).  Every operator code, one level, three elements; laplace_tensor_replace must also leave nothing but the
+    result in its field."""
+    import torch
+    import tinman_sandbox_amd as tsa
+    Dvv = cases.dvv_for(np_, "double" if np_ == 4 else "gll")
+    g = geometry(np_, 3, 21)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+    for name, (oname, okw) in HIP_TO_ORACLE.items():
+        vin = tsa.SPHERE_OPERATORS[name][1]
+        x = cases.uniform((3, 1, np_, np_) + ((2,) if vin else ()), 900 + np_, -2, 3)
+        want = _oracle_all(oracle, oname, x, Dvv, g, 0, **okw)
+        xt = torch.from_numpy(x.copy()).cuda()
+        got = tsa.sphere_operator_ex(name, xt, dev, torch.from_numpy(Dvv).cuda(), RR, nu_ratio=okw.get("nu_ratio", 1.0))
+        torch.cuda.synchronize()
+        if name == "laplace_tensor_replace":
+            assert got.data_ptr() == xt.data_ptr()           # in place
+        else:
+            assert np.array_equal(xt.cpu().numpy(), x), name  # the input is not touched
+        scale = float(np.max(np.abs(want)))
+        assert float(np.max(np.abs(got.cpu().numpy() - want))) <= 1e-12 * scale, (name, np_)
+
+
+@pytest.mark.gpu
 def test_operator_ex_validates_its_arguments():
     import ctypes as C
     import torch
@@ -351,6 +378,15 @@ def test_operator_ex_validates_its_arguments():
     sc = m._CaarOperatorScalars(1.0, 1.0, 0.0, 1.0)
     assert lib.caar_sphere_operator_ex(C.byref(dims), C.byref(geo), C.c_void_p(dvv.data_ptr()), 99, 0, 2, 3,
                                        C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), C.byref(sc), None) == -1
+    # only the in-place code may come without an input pointer
+    for n in ("Dinv", "spheremp", "tensorVisc"):
+        setattr(geo, n, dev[n].data_ptr())
+    code_lt, code_ltr = tsa.SPHERE_OPERATORS["laplace_tensor"][0], tsa.SPHERE_OPERATORS["laplace_tensor_replace"][0]
+    assert lib.caar_sphere_operator_ex(C.byref(dims), C.byref(geo), C.c_void_p(dvv.data_ptr()), code_lt, 0, 2, 3, None,
+                                       C.c_void_p(x.data_ptr()), C.byref(sc), None) == -1
+    assert lib.caar_sphere_operator_ex(C.byref(dims), C.byref(geo), C.c_void_p(dvv.data_ptr()), code_ltr, 0, 2, 3, None,
+                                       C.c_void_p(x.data_ptr()), C.byref(sc), None) == 0
+    torch.cuda.synchronize()
 
 
 @pytest.mark.gpu

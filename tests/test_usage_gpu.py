@@ -505,6 +505,50 @@ def test_context_api_allocates_through_the_placed_allocator(oracle):
         assert np.array_equal(arrs[n][4:], want[n][4:]), n
 
 
+@pytest.mark.parametrize("np_,nlev,rsplit", [(8, 72, 1), (4, 30, 1), (4, 72, 0), (4, 100, 1)])
+def test_launch_steps_without_a_step_loop_kernel_equals_single_calls(np_, nlev, rsplit):
+    """caar_launch_steps where no fused kernel exists (NP=8, other level counts, the Eulerian form): nsteps launches of
+    caar_launch with the rotation in between — bitwise what the host's own loop gives, Control rotated nsteps times."""
+    arrs = cases.hashed_arrays(np_, nlev, 5, seed=400 + np_ + nlev)
+    Dvv = cases.dvv_for(np_)
+    sc = po.default_scalars(nlev)
+    sc.update(dt2=0.125, qn0=1, nets=1, nete=4)
+    if rsplit == 0:
+        sc.update(rsplit=0, hybi=(np.arange(nlev + 1) / nlev) ** 2)
+    a = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    b = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    tsa.compute_and_apply_rhs_steps(a, 4, True)
+    for _ in range(4):
+        tsa.compute_and_apply_rhs(b)
+        b.update_time_levels()
+    torch.cuda.synchronize()
+    assert (a.control.n0, a.control.np1, a.control.nm1) == (b.control.n0, b.control.np1, b.control.nm1)
+    for n in tsa.ARRAY_NAMES:
+        assert torch.equal(a.arrays[n], b.arrays[n]), n
+    L = tsa.library()
+    dims, ptrs, prm = a.arrays.dims(), a.arrays.pointers(), a.params(device_constants=True)
+    import ctypes as C
+    assert L.lib.caar_launch_steps(C.byref(dims), C.byref(ptrs), C.c_void_p(a.dvv_device().data_ptr()), C.byref(prm), 0, 1,
+                                   None) == -1   # nsteps < 1
+
+
+def test_placement_arguments_are_validated():
+    import ctypes as C
+    from tinman_sandbox_amd import caar as m
+    L = tsa.library()
+    dims = m._CaarDims(4, 72, 1, 3, 100)
+    out = m._CaarArrays()
+    for bad in (m._CaarPlacement(7, 0, 0.0), m._CaarPlacement(-1, 0, 0.0), m._CaarPlacement(1, -5, 0.0),
+                m._CaarPlacement(1, 0, 1.5), m._CaarPlacement(1, 0, -0.1)):
+        h = C.c_void_p()
+        assert L.lib.caar_arrays_alloc_ex(C.byref(h), C.byref(dims), 0, C.byref(bad), C.byref(out)) == -1
+        ctx = C.c_void_p()
+        assert L.lib.caar_create_ex(C.byref(ctx), C.byref(dims), 0, C.byref(bad)) == -1
+    h = C.c_void_p()
+    assert L.lib.caar_arrays_alloc_ex(C.byref(h), C.byref(dims), 99, None, C.byref(out)) == -1   # no such device
+    assert L.lib.caar_arrays_free(None) == -1
+
+
 _DEBUG_SCRIPT = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
