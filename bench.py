@@ -50,6 +50,8 @@ def parse():
                     help="also time 20 launches one by one (roofline.kernel_ms_isolated_*)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short extra measurements of BASELINE.json configs[3] and [4]")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 --pmc child passes (the committed figure is used)")
     ap.add_argument("--no-interleaved", action="store_true",
                     help="skip the host-sequence measurements (roofline.interleaved: CAAR alternated with a tracer step / "
                          "a cache-evicting kernel, time levels rotating)")
@@ -146,7 +148,7 @@ def measure_config(np_, nlev, elems, steps, warmup):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--np", str(np_), "--nlev", str(nlev),
            "--elems-per-gpu", str(elems), "--steps", str(steps), "--warmup", str(warmup), "--no-other-configs",
-           "--no-cpu-baseline", "--no-interleaved"]
+           "--no-cpu-baseline", "--no-interleaved", "--no-live-traffic"]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
@@ -225,6 +227,47 @@ def static_traffic(np_, nlev, elems):
 
 TRAFFIC_SOURCE = ("static: profiles/hbm_traffic.json (rocprofv3 --pmc passes committed with the repo; "
                   "not measured in this run; L2-side counters: Infinity-Cache hits are counted as traffic)")
+TRAFFIC_SOURCE_LIVE = ("measured in this run: two child passes of tools/pmc_run.py under rocprofv3 --pmc FETCH_SIZE / "
+                       "--pmc WRITE_SIZE (separate passes, KiB units, each calibrated on the 8 B/lane stream copy of the same "
+                       "pass whose byte count is known, as MI355X_MICROARCH.md prescribes; tools/pmc_parse.py); L2-side "
+                       "counters: Infinity-Cache hits are counted as traffic")
+
+
+def live_traffic(np_, nlev, elems, timeout=240):
+    """HBM-side bytes per launch of the default kernel, measured NOW: the counters need the profiler around the process,
+    so two short child processes run the same launch (same data set size, fresh arrays) under rocprofv3 — one per counter,
+    they do not fit one pass — and tools/pmc_parse.py turns them into bytes.  None if rocprofv3 is not there, this process
+    is itself being profiled, or anything fails (the line then carries the committed figure and says so)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if any("ROCPROF" in k or k.startswith("ROCP_") for k in os.environ) or shutil.which("rocprofv3") is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="caar_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            # python3 itself after `--`: no env / shell hop between the profiler and the program
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, ctr), "--",
+                   sys.executable, os.path.join(ROOT, "tools", "pmc_run.py"), "--np", str(np_), "--nlev", str(nlev),
+                   "--elems", str(elems)]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd="/tmp")
+            if r.returncode != 0:
+                return None
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_parse.py"), os.path.join(tmp, "FETCH_SIZE"),
+                            os.path.join(tmp, "WRITE_SIZE")], capture_output=True, text=True, timeout=60)
+        j = json.loads(r.stdout)
+        return {"bytes": j["hbm_bytes_per_launch"], "read": j["caar_read_bytes_per_launch"],
+                "write": j["caar_write_bytes_per_launch"],
+                "calibration": {"FETCH_SIZE_x": j["counters"]["FETCH_SIZE"]["factor_8B_lane"],
+                                "WRITE_SIZE_x": j["counters"]["WRITE_SIZE"]["factor_8B_lane"]},
+                "kernel": j["counters"]["FETCH_SIZE"]["caar_kernel"]}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def spin_up(tsa, torch, data, stream, dev, block=20, max_blocks=40, tol=0.003):
@@ -565,6 +608,14 @@ def main():
             # (the headline arrays stay allocated: freeing and re-allocating them would change what placement_spread sees)
             out["other_configs"] = [measure_config(4, 72, 12500, 20, 5), measure_config(4, 128, 12500, 20, 5),
                                     measure_config(8, 72, 20000, 10, 3)]
+        if world == 1 and not args.no_live_traffic:
+            # the arrays of this process stay allocated: the children hold their own (2-4 GB) for a few seconds
+            lt = live_traffic(args.np_, args.nlev, mine)
+            if lt is not None:
+                roof["traffic"] = lt["bytes"]
+                roof["traffic_source"] = TRAFFIC_SOURCE_LIVE
+                roof["traffic_detail"] = lt
+                roof["traffic_over_algorithmic"] = lt["bytes"] / per_launch_bytes
         if world == 1 and not args.no_interleaved:
             seqs = interleaved_sequences(tsa, torch, args, data, dev, stream, mine, args.steps)
             roof["interleaved"] = seqs

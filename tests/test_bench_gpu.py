@@ -53,6 +53,11 @@ def test_single_gpu_line_carries_the_contract_and_the_host_sequences():
         assert row["neighbour_ms"] > 0
         for label in ("default", "all_streaming"):
             assert row[label]["sequence_ms"] > row["neighbour_ms"] and row[label]["caar_ms"] > 0
+    import shutil
+    if shutil.which("rocprofv3"):   # HBM-side traffic from the counters, measured by the run itself
+        assert roof["traffic_source"].startswith("measured in this run"), roof["traffic_source"]
+        assert 0.995 <= roof["traffic_over_algorithmic"] <= 1.02, roof["traffic_over_algorithmic"]
+        assert abs(roof["traffic"] - roof["traffic_detail"]["read"] - roof["traffic_detail"]["write"]) < 1.0
     cb = j["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
 

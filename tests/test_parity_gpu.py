@@ -257,6 +257,36 @@ def test_full_size_properties(np_, nlev, E, gold_name):
         assert torch.equal(t, data.arrays[n]), n
 
 
+@pytest.mark.parametrize("nlev,E", [(72, 10000), (128, 12500), (72, 4096)])
+def test_full_size_step_loop_is_bit_identical_to_single_launches(nlev, E):
+    """BASELINE sizes through caar_launch_steps: six calls with rotating time levels as ONE launch (the cache policy the
+    footprint picks: default policy at 10 000 / 12 500 elements, hybrid at 4 096) against the same six calls launched
+    one by one — every array bit for bit, and planted copies of one element agree wherever they sit in the grid."""
+    lib = tsa.library().lib
+    a = tsa.TestData().init_data(E, 4, nlev, device="cuda")
+    b = tsa.TestData().init_data(E, 4, nlev, device="cuda", place="torch")
+    for d in (a, b):
+        d.control.dt2 = 1.0e-3          # keeps six leap-frog steps of the closed-form state finite
+        d.constants.eta_ave_w = 0.5
+        for n in tsa.ARRAY_NAMES:
+            d.arrays[n][E - 1] = d.arrays[n][1]
+            d.arrays[n][E // 2 + 77] = d.arrays[n][1]
+    try:
+        assert lib.caar_get_fused_steps() == 1
+        tsa.compute_and_apply_rhs_steps(a, 6, True)
+        lib.caar_set_fused_steps(0)
+        tsa.compute_and_apply_rhs_steps(b, 6, True)
+    finally:
+        lib.caar_set_fused_steps(1)
+    torch.cuda.synchronize()
+    for n in tsa.ARRAY_NAMES:
+        assert torch.equal(a.arrays[n], b.arrays[n]), n
+        assert torch.isfinite(a.arrays[n]).all(), n
+    for n in tsa.caar.MUTATED:
+        assert torch.equal(a.arrays[n][E - 1], a.arrays[n][1]), n
+        assert torch.equal(a.arrays[n][E // 2 + 77], a.arrays[n][1]), n
+
+
 @pytest.mark.parametrize("np_,nlev", [(4, 72), (8, 72)])
 def test_sphere_operators_match_oracle(oracle, np_, nlev):
     """gradient_sphere / divergence_sphere / vorticity_sphere on their own (S:9-129), driven

@@ -30,7 +30,7 @@ st = torch.cuda.current_stream(dev)
 n_copy = 1 << 27  # 1 GiB each way
 src = torch.ones(n_copy, dtype=torch.float64, device=dev)
 dst = torch.empty_like(src)
-data = tsa.TestData().init_data(a.elems, a.np_, a.nlev, device=dev)
+data = tsa.TestData().init_data(a.elems, a.np_, a.nlev, device=dev, place=tsa.placement("malloc"))  # bytes, not rates
 dims, ptrs, prm = data.arrays.dims(), data.arrays.pointers(), data.params()
 torch.cuda.synchronize()
 for lb in (8, 16):
@@ -42,7 +42,7 @@ if a.np_ == 4:
     for _ in range(3):
         L.check(lib.caar_traffic_skeleton(C.byref(dims), C.byref(ptrs), C.byref(prm), 0, C.c_void_p(st.cuda_stream)), "skel")
     torch.cuda.synchronize()
-    data = tsa.TestData().init_data(a.elems, a.np_, a.nlev, device=dev)
+    data = tsa.TestData().init_data(a.elems, a.np_, a.nlev, device=dev, place=tsa.placement("malloc"))
 if a.rsplit == 0:
     import numpy as np
     data.hvcoord.hybi = (np.arange(a.nlev + 1) / a.nlev) ** 2
