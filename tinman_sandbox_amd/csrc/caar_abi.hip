@@ -44,6 +44,8 @@ hipError_t launch_preq_omega_ps(int np, int nlev, int nelem, const double* p, co
                                 double* omega_p, hipStream_t s);
 hipError_t launch_layout(double* dst, const double* src, size_t n, int np, int nc, int nlev, int qd,
                          int qdp_outer, bool to_caar, hipStream_t s);
+hipError_t launch_layout_all(int np, int count, double* const* dst, const double* const* src, const size_t* n, const int* nc,
+                             const int* qdp_outer, int nlev, int qd, bool to_caar, hipStream_t s);
 hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t stream);
 hipError_t launch_traffic_skeleton_np8(const KernelArgs& k, int nlev, int variant, int num_elems, hipStream_t stream);
 #ifdef CAAR_DEBUG
@@ -668,6 +670,10 @@ static int convert_layout(const CaarDims* d, const CaarArrays* from, const CaarA
                           bool to_caar, bool mutated_only, void* stream) {
   if (!d || !from || !to || e0 < 0 || e1 > d->num_elems || e0 > e1) return CAAR_EINVAL;
   if (d->np != 4 && d->np != 8) return CAAR_EUNSUPPORTED;
+  double* dst[CAAR_NUM_ARRAYS];
+  const double* src[CAAR_NUM_ARRAYS];
+  size_t n[CAAR_NUM_ARRAYS];
+  int nc[CAAR_NUM_ARRAYS], qo[CAAR_NUM_ARRAYS], count = 0;
   for (int i = 0; i < CAAR_NUM_ARRAYS; ++i) {
     bool wanted = !mutated_only;
     for (int m : kMutated) wanted = wanted || m == i;
@@ -677,12 +683,15 @@ static int convert_layout(const CaarDims* d, const CaarArrays* from, const CaarA
     if (!s || !t) return CAAR_EINVAL;
     const long long per = caar_array_len(d, i) / (d->num_elems ? d->num_elems : 1);
     // every array is element-major on both sides, so [e0, e1) is one contiguous range
-    hipError_t e = caar::launch_layout(t + (size_t)per * e0, s + (size_t)per * e0, (size_t)per * (e1 - e0),
-                                       d->np, array_ncomp(i), d->nlev, d->qsize_d, i == 10, to_caar,
-                                       (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
+    dst[count] = t + (size_t)per * e0;
+    src[count] = s + (size_t)per * e0;
+    n[count] = (size_t)per * (e1 - e0);
+    nc[count] = array_ncomp(i);
+    qo[count] = i == 10;
+    ++count;
   }
-  return CAAR_OK;
+  // all arrays of the conversion in one launch (caar_layout.hip)
+  return (int)caar::launch_layout_all(d->np, count, dst, src, n, nc, qo, d->nlev, d->qsize_d, to_caar, (hipStream_t)stream);
 }
 
 int caar_layout_from_f90(const CaarDims* dims, const CaarArrays* f90_dev, const CaarArrays* caar_dev, int e0,
