@@ -70,7 +70,7 @@ enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, 
 // The workgroup's LDS, declared ONCE in the kernel and shared by the code paths instantiated inside it (the
 // hybrid cache policy compiles the element body twice; as function-local __shared__ arrays every buffer
 // existed twice: 17.4 KB instead of 8.7 KB at NLEV=72).
-template <int NLEV_T, int TPW, bool PERSIST, bool VADV, int DYNW, int PARK = 0>
+template <int NLEV_T, int TPW, bool PERSIST, bool VADV, int DYNW, int PARK = 0, bool CARRY_LDS = false>
 struct Np4Lds {
   static constexpr int PP = 16;
   static constexpr int NT_MAX = NLEV_T == 0 ? DYNW * TPW : (NLEV_T + 3) / 4;
@@ -89,6 +89,9 @@ struct Np4Lds {
   // u, v, T are re-read from `col` in the last phase instead of staying in registers
   static constexpr int NPARK = (PARK & 1) + ((PARK >> 1) & 1) + ((PARK >> 2) & 1) + ((PARK >> 3) & 1) + ((PARK >> 4) & 1);
   double park[NPARK ? NPARK : 1][NPARK ? NT_MAX * 64 : 1];
+  // CARRY_LDS (step loop): what the NEXT call will read as u, v, T, dp3d at nm1 (= this call's n0 state) and the tracer
+  // block, handed from call to call in LDS ([slot][tile * 64 + lane]; each lane re-reads only what it wrote)
+  double carry[CARRY_LDS ? 5 : 1][CARRY_LDS ? NT_MAX * 64 : 1];
 };
 
 // PARK: the five per-point values that live from the scans to the last phase (p, divdp prefix, hydrostatic in-tile suffix,
@@ -98,11 +101,28 @@ struct Np4Lds {
 // the column copy).  The re-reads go through lds_reread_ptr (plain ds_read_b64): near free, 82.9 % against 83.6 % unparked at
 // NLEV=72.  (Round 2 first had them as `volatile` generic loads = flat_load sc0 sc1 + s_waitcnt vmcnt(0), which drained the
 // global loads in flight at every parked read: 75.4 %.)
+// The n0 inputs of a wave's tiles (dp3d, u, v, T at time level n0; the tracer mass Qdp).  The step loop
+// (caar_np4_steps_kernel) carries one of these from call to call: what a lane stores at np1 is what it would load as n0
+// in the next call, so it keeps the values instead (CARRY).
+template <int TPW>
+struct Np4N0In {
+  double dp[TPW], u[TPW], v[TPW], T[TPW], q[TPW];
+};
+
 // STEPS: the body runs inside the step loop of caar_np4_steps_kernel (several calls of the routine by one workgroup): the
 // barriers drain the LDS counter only, like the persistent form's, so that a step's first barrier does not wait for the
 // previous step's stores.
-template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW, int PARK = 0, bool STEPS = false>
-__device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW, PARK>& lds) {
+// CARRY_IN (compile time; STEPS only), what the previous call of the step loop handed over: bit 1 = `carry` holds this
+// call's n0 state (dp3d, u, v, T), 2 = lds.carry holds its nm1 state, 4 = lds.carry holds its tracer block (2 and 4 only
+// with CARRY_LDS).  Every STEPS call hands the same things on to the next one.
+template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW, int PARK = 0, bool STEPS = false, bool CARRY_LDS = false, int CARRY_IN = 0>
+__device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW, PARK, CARRY_LDS>& lds,
+                                                 Np4N0In<TPW>* carry = nullptr) {
+  static_assert(!CARRY_LDS || STEPS, "CARRY_LDS: step loop only");
+  static_assert(CARRY_IN == 0 || STEPS, "CARRY_IN: step loop only");
+  static_assert(CARRY_LDS || (CARRY_IN & 6) == 0, "nm1 / tracer carry needs CARRY_LDS");
+  constexpr int carry_flags = CARRY_IN;
+  constexpr bool carry_valid = STEPS && (CARRY_IN & 1);
   constexpr int PP = 16;               // GLL points per level
   constexpr bool DYN = NLEV_T == 0;
   constexpr int NT_MAX = DYN ? DYNW * TPW : (NLEV_T + 3) / 4;  // LDS sizing
@@ -149,9 +169,8 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   unsigned eb = blockIdx.x;  // PERSIST: element counter relative to nets
 
   // n0 inputs of this wave's tiles
-  struct N0In {
-    double dp[TPW], u[TPW], v[TPW], T[TPW], q[TPW];
-  };
+  using N0In = Np4N0In<TPW>;
+  static_assert(!STEPS || (!PERSIST && !RAGGED && !VADV), "step loop: plain Lagrangian form");
   auto load_n0 = [&](size_t ie) {
     const double* __restrict__ dp_n0 = k.dp3d + (ie * tl + k.n0) * BLK + wbase;
     const dbl2* __restrict__ v_n0 = reinterpret_cast<const dbl2*>(k.v + (ie * tl + k.n0) * BLK * 2) + wbase;
@@ -186,7 +205,29 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   static_assert(!PERSIST || NT_MAX / TPW * 64 >= G_SIZE, "persistent form stages one metric value per thread");
 
   // ---- phase 0: issue the n0 loads of the first element --------------------------------
-  N0In in = load_n0((size_t)ie_s);
+  // STEPS: `in` is the caller's carry.  carry_valid (uniform): it already holds this call's n0 state — the previous call's
+  // np1 results, bit for bit what a load would return — so only the tracer block is requested.
+  N0In in_local;
+  N0In& in = STEPS ? *carry : in_local;
+  if (STEPS && carry_valid) {
+    if (CARRY_LDS && (carry_flags & 4)) {
+      const lds_cptr cq = lds_reread_ptr(&lds.carry[4][0] + (size_t)w * (TPW * 64) + lane);
+#pragma unroll
+      for (int r = 0; r < TPW; ++r) in.q[r] = MOIST ? cq[r * 64] : 0.0;
+    } else {
+      const double* __restrict__ Qdp = k.Qdp + (((size_t)ie_s * k.qsize_d + 0) * 2 + (MOIST ? k.qn0 : 0)) * BLK + wbase;
+#pragma unroll
+      for (int r = 0; r < TPW; ++r) in.q[r] = MOIST ? stream_load<SNT>(Qdp + r * 64 + ulane) : 0.0;
+    }
+  } else {
+    in = load_n0((size_t)ie_s);
+  }
+  if constexpr (CARRY_LDS && MOIST) {
+    if (!(carry_flags & 4)) {  // first call: the tracer block does not change from call to call (qn0 is fixed)
+#pragma unroll
+      for (int r = 0; r < TPW; ++r) lds.carry[4][(w * TPW + r) * 64 + lane] = in.q[r];
+    }
+  }
   double geo_reg = 0.0;
   if (PERSIST && tid < G_SIZE) geo_reg = *geo_src((size_t)ie_s, tid);
   if (tid < 16) s_dvv[tid] = k.Dvv[tid];
@@ -236,9 +277,18 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       const unsigned off = r * 64 + ulane;
       TileIn x = {};
       if (!live_row(r)) return x;
-      x.vnm1 = stream_load<SNT>(v_nm1 + off);
-      x.Tnm1 = stream_load<SNT>(T_nm1 + off);
-      x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
+      if (CARRY_LDS && (carry_flags & 2)) {  // the previous call parked its n0 state: this call's nm1
+        const lds_cptr cn = lds_reread_ptr(&lds.carry[0][0] + (w * TPW + r) * 64 + lane);
+        constexpr int Q = NT_MAX * 64;
+        x.vnm1.x = cn[0];
+        x.vnm1.y = cn[Q];
+        x.Tnm1 = cn[2 * Q];
+        x.dpnm1 = cn[3 * Q];
+      } else {
+        x.vnm1 = stream_load<SNT>(v_nm1 + off);
+        x.Tnm1 = stream_load<SNT>(T_nm1 + off);
+        x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
+      }
       x.vn0 = stream_load<ANT>(vn0 + off);
       x.om = stream_load<ANT>(omega_p + off);
       x.pec = stream_load<SNT>(pecnd + off);
@@ -417,15 +467,15 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
 
       double gp0, gp1;
       gradient_sphere(c, Dinv, rrearth, p_r, gp0, gp1);            // P:103
-      const double vgrad_p = u_r * gp0 + v_r * gp1;               // P:111
+      const double vgrad_p = dot2(u_r, gp0, v_r, gp1);            // P:111
       const double ckk = 0.5 * rp_r, ckl = rp_r;                  // P:333-334 (ckl = 2*ckk)
-      const double om = vgrad_p * rp_r - ckl * suml_r - ckk * divdp_r;  // P:325,336,348
+      const double om = __builtin_fma(-ckk, divdp_r, __builtin_fma(vgrad_p, rp_r, -(ckl * suml_r)));  // P:325,336,348
       const double vort = vorticity_sphere(c, Dm, rmetdet, rrearth, u_r, v_r);  // P:122
 
-      const double Ephi = 0.5 * (u_r * u_r + v_r * v_r) + phi + cur.pec;  // P:196
+      const double Ephi = 0.5 * dot2(u_r, u_r, v_r, v_r) + phi + cur.pec;  // P:196
       double gT0, gT1, gE0, gE1;
       gradient_sphere(c, Dinv, rrearth, T_r, gT0, gT1);            // P:200
-      const double vgrad_T = u_r * gT0 + v_r * gT1;               // P:209
+      const double vgrad_T = dot2(u_r, gT0, v_r, gT1);            // P:209
       gradient_sphere(c, Dinv, rrearth, Ephi, gE0, gE1);            // P:213
       const double gpterm = Tv_r * rp_r;                          // P:219
       const double glnps1 = k.Rgas * gpterm * gp0;                  // P:221
@@ -459,7 +509,8 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       vo.x = spheremp * (cur.vnm1.x + k.dt2 * vtens1);              // P:251
       vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);              // P:252
       stream_store<SNT>(v_np1 + off, vo);
-      stream_store<SNT>(T_np1 + off, spheremp * (cur.Tnm1 + k.dt2 * ttens));        // P:253
+      const double T_new = spheremp * (cur.Tnm1 + k.dt2 * ttens);                     // P:253
+      stream_store<SNT>(T_np1 + off, T_new);
       const double dp_new = VADV ? spheremp * (cur.dpnm1 - k.dt2 * (divdp_r + eta_hi - eta_lo))   // X:515-517
                                  : spheremp * (cur.dpnm1 - k.dt2 * divdp_r);                       // P:254
       debug_check_dp3d(dp_new);  // CaarFunctor.hpp:82-97 check_dp3d (-DCAAR_DEBUG builds only)
@@ -477,6 +528,23 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         // then keeps the array bit-identical to the reference's and drops the write traffic.
         if (!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(cur.eta))
           stream_store<ANT>(eta + off, e_new);
+      }
+      if constexpr (CARRY_LDS) {  // this call's n0 state is the next call's nm1
+        lds.carry[0][t * 64 + lane] = u_r;
+        lds.carry[1][t * 64 + lane] = v_r;
+        lds.carry[2][t * 64 + lane] = T_r;
+        lds.carry[3][t * 64 + lane] = dp[r];
+      }
+      if constexpr (STEPS) {  // the state just stored at np1 is the next call's n0 (update_time_levels): keep it
+        // (through an opaque move: the next call must treat these exactly like loaded values — with their producing
+        // multiplies in sight the compiler contracts the next call's first operations differently, a last-bit difference
+        // from the single launches)
+        double cu = vo.x, cv = vo.y, cT = T_new, cdp = dp_new;
+        asm volatile("" : "+v"(cu), "+v"(cv), "+v"(cT), "+v"(cdp));
+        in.u[r] = cu;
+        in.v[r] = cv;
+        in.T[r] = cT;
+        in.dp[r] = cdp;
       }
       cur = nxt;
     }

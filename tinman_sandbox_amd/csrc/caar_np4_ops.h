@@ -51,6 +51,13 @@ __device__ __forceinline__ double d_db(const RowCoef& c, double f) {
   return s;
 }
 
+// a*b + c*d with the contraction spelled out: c*d is rounded, a*b is fused into the sum.  Left to the compiler
+// (-ffp-contract=fast) either product may be the fused one, and which one it picks depends on how the operands reached
+// the expression (loaded, carried in registers, ...): two instantiations of the same kernel body can then differ in the
+// last bit.  With every sum of two products written this way all NP=4 kernels — every launch shape, cache policy, the
+// step loop with its carried state — perform the same roundings and give bit-identical results.
+__device__ __forceinline__ double dot2(double a, double b, double c, double d) { return __builtin_fma(a, b, c * d); }
+
 // Metric 2x2 of this lane's point, row-major m[r][c] -> {m00, m01, m10, m11}.
 struct M22 {
   double m00, m01, m10, m11;
@@ -61,21 +68,21 @@ __device__ __forceinline__ void gradient_sphere(const RowCoef& c, const M22& Din
                                                 double s, double& g0, double& g1) {
   const double v1 = d_da(c, s) * rrearth;
   const double v2 = d_db(c, s) * rrearth;
-  g0 = Dinv.m00 * v1 + Dinv.m10 * v2;
-  g1 = Dinv.m01 * v1 + Dinv.m11 * v2;
+  g0 = dot2(Dinv.m00, v1, Dinv.m10, v2);
+  g1 = dot2(Dinv.m01, v1, Dinv.m11, v2);
 }
 // divergence_sphere, S:50-89
 __device__ __forceinline__ double divergence_sphere(const RowCoef& c, const M22& Dinv, double metdet,
                                                     double rmetdet, double rrearth, double u, double v) {
-  const double gv0 = metdet * (Dinv.m00 * u + Dinv.m01 * v);
-  const double gv1 = metdet * (Dinv.m10 * u + Dinv.m11 * v);
+  const double gv0 = metdet * dot2(Dinv.m00, u, Dinv.m01, v);
+  const double gv1 = metdet * dot2(Dinv.m10, u, Dinv.m11, v);
   return (d_da(c, gv0) + d_db(c, gv1)) * rmetdet * rrearth;
 }
 // vorticity_sphere, S:91-129
 __device__ __forceinline__ double vorticity_sphere(const RowCoef& c, const M22& D, double rmetdet,
                                                    double rrearth, double u, double v) {
-  const double vc0 = D.m00 * u + D.m10 * v;
-  const double vc1 = D.m01 * u + D.m11 * v;
+  const double vc0 = dot2(D.m00, u, D.m10, v);
+  const double vc1 = dot2(D.m01, u, D.m11, v);
   return (d_da(c, vc1) - d_db(c, vc0)) * rmetdet * rrearth;
 }
 

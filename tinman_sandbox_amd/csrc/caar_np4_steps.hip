@@ -33,31 +33,60 @@ __device__ __forceinline__ KernelArgs reload_args() {
 }
 static_assert(sizeof(KernelArgs) == 18 * 8 + 12 * 4 + 7 * 8, "reload_args lists every member of KernelArgs");
 
-template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, int PARK>
-__global__ __launch_bounds__((NLEV_T + 3) / 4 / TPW * 64, MINW) void caar_np4_steps_kernel(const KernelArgs k0, int nsteps, int rotate) {
-  __shared__ Np4Lds<NLEV_T, TPW, false, false, 8, PARK> lds;
-  const long long ie_s = element_of_block(k0, blockIdx.x);
-  if (ie_s < 0) return;
-  const bool keep = POL == 2 && element_is_cached(k0, ie_s - k0.nets);
+// The loop over the calls for one cache policy (SNT / ANT: non-temporal element arrays / accumulators).  The hybrid policy
+// picks one of two such loops per workgroup: with both bodies inside ONE loop the carried state is live across either and
+// the kernel spills 54-71 VGPRs.
+// With rotating, distinct time levels (the driver loop) the first call loads everything and every later call takes its n0
+// state from registers and (CARRY_LDS) its nm1 state and tracer block from LDS — two instantiations of the body, the
+// steady one with no n0 / nm1 / Qdp loads at all.  Without rotation, or with aliased time levels, every call loads
+// what it reads (what a lane stored is what it loads: same results, no carry).
+template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, int PARK, bool CARRY_LDS>
+__device__ __forceinline__ void np4_step_loop(const KernelArgs& k0, int nsteps, int rotate,
+                                              Np4Lds<NLEV_T, TPW, false, false, 8, PARK, CARRY_LDS>& lds) {
   int n0 = k0.n0, np1 = k0.np1, nm1 = k0.nm1;
-  for (int s = 0; s < nsteps; ++s) {
+  Np4N0In<TPW> carry;  // dp3d, u, v, T at n0 of this wave's tiles, handed from call to call in registers
+  const bool steady = rotate && n0 != np1 && n0 != nm1 && np1 != nm1;  // uniform
+  auto rotate_levels = [&] {  // TestData::update_time_levels
+    const int t = np1;
+    np1 = nm1;
+    nm1 = n0;
+    n0 = t;
+  };
+  auto args = [&] {
     KernelArgs k = reload_args();
     k.n0 = n0;
     k.np1 = np1;
     k.nm1 = nm1;
-    if constexpr (POL == 2) {
-      if (keep) caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, false, PF, false, false, false, 8, PARK, true>(k, lds);
-      else caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, true, PF, false, false, false, 8, PARK, true>(k, lds);
-    } else {
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, POL == 1, POL == 1, PF, false, false, false, 8, PARK, true>(k, lds);
+    return k;
+  };
+  if (steady) {
+    caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0>(args(), lds, &carry);
+    for (int s = 1; s < nsteps; ++s) {
+      rotate_levels();
+      wg_barrier<true>();  // the next call re-stages Dvv and the metric terms in LDS: everybody is done reading them
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CARRY_LDS ? 7 : 1>(args(), lds, &carry);
     }
-    if (rotate) {  // TestData::update_time_levels
-      const int t = np1;
-      np1 = nm1;
-      nm1 = n0;
-      n0 = t;
+  } else {
+    for (int s = 0; s < nsteps; ++s) {
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0>(args(), lds, &carry);
+      if (rotate) rotate_levels();
+      wg_barrier<true>();
     }
-    wg_barrier<true>();  // the next call re-stages Dvv and the metric terms in LDS: everybody is done reading them
+  }
+}
+
+// CARRY_LDS: the nm1 state and the tracer block travel from call to call in LDS (NLEV=72: 46 KB more, two workgroups per CU
+// still fit; NLEV=128 has no room next to its parked scan results).
+template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, int PARK, bool CARRY_LDS>
+__global__ __launch_bounds__((NLEV_T + 3) / 4 / TPW * 64, MINW) void caar_np4_steps_kernel(const KernelArgs k0, int nsteps, int rotate) {
+  __shared__ Np4Lds<NLEV_T, TPW, false, false, 8, PARK, CARRY_LDS> lds;
+  const long long ie_s = element_of_block(k0, blockIdx.x);
+  if (ie_s < 0) return;
+  if constexpr (POL == 2) {
+    if (element_is_cached(k0, ie_s - k0.nets)) np4_step_loop<NLEV_T, TPW, MINW, MOIST, true, false, PF, PARK, CARRY_LDS>(k0, nsteps, rotate, lds);
+    else np4_step_loop<NLEV_T, TPW, MINW, MOIST, true, true, PF, PARK, CARRY_LDS>(k0, nsteps, rotate, lds);
+  } else {
+    np4_step_loop<NLEV_T, TPW, MINW, MOIST, POL == 1, POL == 1, PF, PARK, CARRY_LDS>(k0, nsteps, rotate, lds);
   }
 }
 
@@ -67,9 +96,9 @@ static hipError_t launch_np4_steps(const KernelArgs& k, int num_elems, int nstep
   if (k.vadv) return hipErrorNotSupported;  // the Eulerian form steps through the graph of single launches
   const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
   if (k.qn0 >= 0)
-    hipLaunchKernelGGL((caar_np4_steps_kernel<NLEV, TPW, MINW, true, POL, PF, PARK>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
+    hipLaunchKernelGGL((caar_np4_steps_kernel<NLEV, TPW, MINW, true, POL, PF, PARK, (NLEV <= 72)>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
   else
-    hipLaunchKernelGGL((caar_np4_steps_kernel<NLEV, TPW, MINW, false, POL, PF, PARK>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
+    hipLaunchKernelGGL((caar_np4_steps_kernel<NLEV, TPW, MINW, false, POL, PF, PARK, (NLEV <= 72)>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
   return hipGetLastError();
 }
 
@@ -86,13 +115,13 @@ CAAR_STEPS(128, 8, 2, 1, 0, 27)
 CAAR_STEPS(128, 8, 2, 0, 0, 27)
 #undef CAAR_STEPS
 
-// What the default variants use: the cache policy of the step loop by footprint.  Data sets well beyond the 256 MB
-// Infinity Cache run fastest with the default policy for everything (a call's outputs are the next call's inputs and are
-// still on chip: 7.5 TB/s algorithmic at 10 000 elements against 7.2 hybrid and 6.4 all-streaming); smaller ones with the
-// hybrid policy, whose streaming accesses leave the cache to the accumulators (7.8 against 7.4 at 4 096 elements).
-// profiles/r03/steps_bench_72.log, steps_bench_128.log.
+// What the default variants use.  From the second call on a call's inputs are the previous call's outputs: n0 state in
+// registers, (NLEV=72) nm1 state and tracer block in LDS, the rest still on chip if the accesses use the DEFAULT cache
+// policy — the opposite of what a single call wants.  NLEV=72: default policy at every size (0.221 ms per call at 10 000
+// elements against 0.244 all-streaming and 0.322 for single launches; 23 us against 30 hybrid at 1 024).  NLEV=128 (no LDS
+// carry): hybrid is 3 % ahead below ~3 700 elements, equal above.  profiles/r03/steps_bench_72_final.log, _128_final.log.
 hipError_t launch_np4_steps_72_auto(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) {
-  return num_elems >= 6500 ? launch_np4_steps_72_0(k, num_elems, nsteps, rotate, s) : launch_np4_steps_72_2(k, num_elems, nsteps, rotate, s);
+  return launch_np4_steps_72_0(k, num_elems, nsteps, rotate, s);
 }
 hipError_t launch_np4_steps_128_auto(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) {
   return num_elems >= 3700 ? launch_np4_steps_128_0(k, num_elems, nsteps, rotate, s) : launch_np4_steps_128_2(k, num_elems, nsteps, rotate, s);
