@@ -543,8 +543,11 @@ def test_fused_steps_are_bit_identical_to_the_graph_of_single_launches(oracle, n
     try:
         for variant in fused_variants:
             assert lib.caar_select_variant(4, nlev, variant) == 0
+            # rotating distinct levels (the carried-state path), a dry sub-range, no rotation, another starting permutation,
+            # and aliased time levels with rotation (n0 == np1; nm1 == n0: every call loads what it reads)
             for extra, nsteps, rotate in ((dict(), 5, 1), (dict(qn0=-1, nets=3, nete=30), 4, 1), (dict(dt2=0.125), 3, 0),
-                                          (dict(n0=2, np1=0, nm1=1), 1, 1)):
+                                          (dict(n0=2, np1=0, nm1=1), 4, 1), (dict(n0=1, np1=1, nm1=0), 3, 1),
+                                          (dict(n0=0, np1=1, nm1=0), 3, 1), (dict(n0=2, np1=2, nm1=1), 2, 0)):
                 sc = po.default_scalars(nlev)
                 sc.update(dt2=0.25, qn0=1)
                 sc.update(extra)
