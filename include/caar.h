@@ -404,12 +404,15 @@ int caar_run(CaarContext *ctx, const CaarParams *params);
  * params, nsteps and rotate stay the same.  Asynchronous. */
 int caar_run_steps(CaarContext *ctx, const CaarParams *params, int nsteps, int rotate);
 /* How caar_run_steps issues the calls.  1 (default): as ONE kernel launch where the selected variant has a step-loop
- * kernel (NP=4, NLEV 72 / 128, rsplit > 0) — elements are independent and every lane only ever touches its own points,
+ * kernel (NP=4 NLEV 72 / 128 and NP=8 NLEV 72, rsplit > 0) — elements are independent and every lane only ever touches its own points,
  * so each workgroup makes all nsteps calls for its element back to back: launch fill/drain once per nsteps instead of
  * once per call, the element's arrays still in cache from the second call on; bit-identical to single launches.
  * 0: always a hipGraph of nsteps single launches (what every other configuration uses).  Process-wide, atomic. */
 int caar_set_fused_steps(int on);
 int caar_get_fused_steps(void);
+/* 1 if tuning variant `variant` of (np, nlev) has a step-loop kernel (NP=4 NLEV 72 / 128: the two-workgroup shapes; NP=8: the
+ * MFMA forms), else 0. */
+int caar_has_fused_steps(int np, int nlev, int variant);
 /* Wait for everything enqueued on the context stream. */
 int caar_sync(CaarContext *ctx);
 /* Device pointers / stream of the context (for callers that launch their own work). */

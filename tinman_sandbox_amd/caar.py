@@ -101,7 +101,7 @@ class CaarLibrary:
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
                "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_selected_variant", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_stream_copy_tuned", "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_arrays_alloc", "caar_arrays_alloc_ex", "caar_arrays_free", "caar_arrays_placement", "caar_create", "caar_create_ex", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_upload_f90_arrays", "caar_download_f90",
                "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
-               "caar_time_runs", "caar_run_steps", "caar_set_fused_steps", "caar_get_fused_steps", "caar_map_host", "caar_run_mapped", "caar_unmap_host")
+               "caar_time_runs", "caar_run_steps", "caar_set_fused_steps", "caar_get_fused_steps", "caar_has_fused_steps", "caar_map_host", "caar_run_mapped", "caar_unmap_host")
 
     def __init__(self, path=LIB_PATH):
         if not os.path.exists(path):
@@ -185,6 +185,7 @@ class CaarLibrary:
         L.caar_time_runs.argtypes = [vp, C.POINTER(_CaarParams), C.c_int, C.POINTER(C.c_float)]
         L.caar_run_steps.argtypes = [vp, C.POINTER(_CaarParams), C.c_int, C.c_int]
         L.caar_set_fused_steps.argtypes = [C.c_int]
+        L.caar_has_fused_steps.argtypes = [C.c_int, C.c_int, C.c_int]
         L.caar_map_host.argtypes = [C.POINTER(vp), C.POINTER(_CaarDims), C.POINTER(_CaarArrays), C.c_int]
         L.caar_run_mapped.argtypes = [vp, C.POINTER(_CaarParams)]
         L.caar_unmap_host.argtypes = [vp]

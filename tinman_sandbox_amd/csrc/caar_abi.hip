@@ -257,6 +257,11 @@ int caar_set_fused_steps(int on) {
 
 int caar_get_fused_steps(void) { return g_fused_steps.load(); }
 
+int caar_has_fused_steps(int np, int nlev, int variant) {
+  const caar::Config* c = caar::find_config(np, nlev);
+  return (c && variant >= 0 && variant < c->count && c->variants[variant].launch_steps) ? 1 : 0;
+}
+
 int caar_set_xcd_chunked(int on) {
   g_xcd_chunked.store(on < 0 ? -1 : (on ? 1 : 0));
   return CAAR_OK;

@@ -86,6 +86,14 @@ __device__ __forceinline__ double recip(double x) {
   return r;
 }
 
+// a*b + c*d with the contraction spelled out: c*d is rounded, a*b is fused into the sum.  Left to the compiler
+// (-ffp-contract=fast) either product may be the fused one, and which one it picks depends on how the operands reached
+// the expression (loaded, carried in registers, ...): two instantiations of the same kernel body can then differ in the
+// last bit.  With every sum of two products written this way all kernels of one NP — every launch shape, cache policy, the
+// step loops with their carried state — perform the same roundings and give bit-identical results.
+__device__ __forceinline__ double dot2(double a, double b, double c, double d) { return __builtin_fma(a, b, c * d); }
+
+
 // Streaming accesses.  Every element array is read once and written once per launch
 // and never re-used by another workgroup, so the loads and stores carry the
 // non-temporal hint ("nt"): measured +5..8 % bandwidth on the traffic skeleton when
@@ -112,6 +120,27 @@ __device__ __forceinline__ lds_cptr lds_reread_ptr(const double* generic_ptr_int
   asm volatile("" : "+v"(a));
   return (lds_cptr)(size_t)a;
 }
+
+// The kernel arguments are RE-READ from the kernarg segment at the top of every call (scalar loads through a laundered
+// pointer): kept alive across the loop, the 16 array pointers and the scalars would hold ~70 SGPRs for the whole kernel,
+// the overflow is spilled into VGPR lanes, and the NP=4 two-workgroup shapes no longer fit 256 VGPRs (measured: 270-283
+// VGPRs that way; as it stands the kernels are at the register count of their single-call twins).  Used by the step-loop
+// kernels (caar_np4_steps.hip, caar_np8.hip), whose first kernel parameter is the KernelArgs.
+typedef const __attribute__((address_space(4))) KernelArgs* kernarg_ptr;
+__device__ __forceinline__ KernelArgs reload_args() {
+  kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();  // KernelArgs is the first kernel parameter
+  asm volatile("" : "+s"(kp));
+  KernelArgs k;
+#define CAAR_F(f) k.f = kp->f;
+  CAAR_F(D) CAAR_F(Dinv) CAAR_F(fcor) CAAR_F(spheremp) CAAR_F(metdet) CAAR_F(rmetdet) CAAR_F(dp3d) CAAR_F(v) CAAR_F(T)
+  CAAR_F(phis) CAAR_F(Qdp) CAAR_F(eta_dot_dpdn) CAAR_F(omega_p) CAAR_F(phi) CAAR_F(pecnd) CAAR_F(vn0) CAAR_F(Dvv)
+  CAAR_F(hybi) CAAR_F(vadv) CAAR_F(nets) CAAR_F(nelem) CAAR_F(per_xcd) CAAR_F(cache_count) CAAR_F(n0) CAAR_F(np1)
+  CAAR_F(nm1) CAAR_F(qn0) CAAR_F(qsize_d) CAAR_F(timelevels) CAAR_F(nlev) CAAR_F(dt2) CAAR_F(rrearth) CAAR_F(eta_ave_w)
+  CAAR_F(rv_over_rd_m1) CAAR_F(Rgas) CAAR_F(kappa) CAAR_F(p_top)
+#undef CAAR_F
+  return k;
+}
+static_assert(sizeof(KernelArgs) == 18 * 8 + 12 * 4 + 7 * 8, "reload_args lists every member of KernelArgs");
 
 // -DCAAR_DEBUG builds (libcaar_hip_debug.so): the reference's only hot-path assertion, check_dp3d
 // (level_vectorized_ppscan/CaarFunctor.hpp:82-97: dp3d(np1) > 0 under !NDEBUG), as a device-side counter instead of an

@@ -51,13 +51,6 @@ __device__ __forceinline__ double d_db(const RowCoef& c, double f) {
   return s;
 }
 
-// a*b + c*d with the contraction spelled out: c*d is rounded, a*b is fused into the sum.  Left to the compiler
-// (-ffp-contract=fast) either product may be the fused one, and which one it picks depends on how the operands reached
-// the expression (loaded, carried in registers, ...): two instantiations of the same kernel body can then differ in the
-// last bit.  With every sum of two products written this way all NP=4 kernels — every launch shape, cache policy, the
-// step loop with its carried state — perform the same roundings and give bit-identical results.
-__device__ __forceinline__ double dot2(double a, double b, double c, double d) { return __builtin_fma(a, b, c * d); }
-
 // Metric 2x2 of this lane's point, row-major m[r][c] -> {m00, m01, m10, m11}.
 struct M22 {
   double m00, m01, m10, m11;

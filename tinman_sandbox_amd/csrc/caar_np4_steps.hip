@@ -13,26 +13,6 @@ namespace caar {
 // nsteps calls instead of once per call, and from the second call on the element's arrays are still in the L2 / Infinity
 // Cache of the XCD that wrote them (POL = 0: default cache policy; ~95 MB in flight over the chip).  Each call is the same
 // code as caar_np4_kernel's (caar_np4_element): bit-identical to nsteps single launches.
-// The kernel arguments are RE-READ from the kernarg segment at the top of every call (scalar loads through a laundered
-// pointer): kept alive across the loop, the 16 array pointers and the scalars would hold ~70 SGPRs for the whole kernel,
-// the overflow is spilled into VGPR lanes, and the two-workgroup shapes no longer fit 256 VGPRs (measured: 270-283
-// VGPRs that way; as it stands the kernels are at the register count of their single-call twins).
-typedef const __attribute__((address_space(4))) KernelArgs* kernarg_ptr;
-__device__ __forceinline__ KernelArgs reload_args() {
-  kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();  // KernelArgs is the first kernel parameter
-  asm volatile("" : "+s"(kp));
-  KernelArgs k;
-#define CAAR_F(f) k.f = kp->f;
-  CAAR_F(D) CAAR_F(Dinv) CAAR_F(fcor) CAAR_F(spheremp) CAAR_F(metdet) CAAR_F(rmetdet) CAAR_F(dp3d) CAAR_F(v) CAAR_F(T)
-  CAAR_F(phis) CAAR_F(Qdp) CAAR_F(eta_dot_dpdn) CAAR_F(omega_p) CAAR_F(phi) CAAR_F(pecnd) CAAR_F(vn0) CAAR_F(Dvv)
-  CAAR_F(hybi) CAAR_F(vadv) CAAR_F(nets) CAAR_F(nelem) CAAR_F(per_xcd) CAAR_F(cache_count) CAAR_F(n0) CAAR_F(np1)
-  CAAR_F(nm1) CAAR_F(qn0) CAAR_F(qsize_d) CAAR_F(timelevels) CAAR_F(nlev) CAAR_F(dt2) CAAR_F(rrearth) CAAR_F(eta_ave_w)
-  CAAR_F(rv_over_rd_m1) CAAR_F(Rgas) CAAR_F(kappa) CAAR_F(p_top)
-#undef CAAR_F
-  return k;
-}
-static_assert(sizeof(KernelArgs) == 18 * 8 + 12 * 4 + 7 * 8, "reload_args lists every member of KernelArgs");
-
 // The loop over the calls for one cache policy (SNT / ANT: non-temporal element arrays / accumulators).  The hybrid policy
 // picks one of two such loops per workgroup: with both bodies inside ONE loop the carried state is live across either and
 // the kernel spills 54-71 VGPRs.

@@ -39,9 +39,35 @@ namespace caar {
 // mapping becomes the MFMA result layout (mfma_point), the wave-private LDS tile and the LDS Dvv copy are not
 // used at all, everything else is unchanged.
 // LA: how many levels ahead the update-phase inputs (nm1 state, vn0, omega_p, pecnd, eta) are requested.
-template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T, bool BATCH, bool VADV = false, bool MFMA = false, int LA = 1>
-__global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const KernelArgs k) {
+// The workgroup's LDS, declared ONCE in each kernel and shared by the instantiations of the body inside it (the step loop has
+// two: as function-local __shared__ arrays every buffer would exist twice, 260 KB).
+template <int NLEV, int TPW, bool BATCH, bool VADV, bool MFMA>
+struct Np8Lds {
+  static constexpr int WAVES = NLEV / TPW, BLK = NLEV * np8::PP, SLOTS = BATCH ? 5 : 1;
+  __attribute__((aligned(16))) double dvvT[64];
+  __attribute__((aligned(16))) double geo[np8::G_SIZE];
+  __attribute__((aligned(16))) double tile[MFMA ? 1 : WAVES * 64 * SLOTS];  // LDS tile slots per wave (BATCH: p, T, Ephi, vcov1, vcov0)
+  double park[3 * BLK + (VADV ? np8::PP : 0)];  // dp, u, v of every level, [field][lev][pt] (+ a zero row for VADV)
+  double tot_dp[WAVES * np8::PP];               // per wave: sum of dp over its levels
+  double tot_div[WAVES * np8::PP];              // ... of divdp
+  double tot_ht[WAVES * np8::PP];               // ... of Rgas*T_v*dp/p
+  double Thalo[VADV ? WAVES * 2 * np8::PP : 1]; // VADV: T of each wave's first / last level
+};
+
+// STEPS: the body runs inside the step loop of caar_np8_steps_kernel (see caar_np4_steps.hip for the idea): barriers drain
+// the LDS counter only, and the call hands its np1 results to the next one — dp3d, u, v through the LDS park they already
+// live in, T through `Tc` (registers).  CARRY_IN (compile time): this call's n0 state arrives that way instead of being
+// loaded (every lane reads and writes only its own points, so what it stored is what it would load).
+template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T, bool BATCH, bool VADV = false, bool MFMA = false, int LA = 1,
+          bool STEPS = false, bool CARRY_IN = false>
+__device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLEV, TPW, BATCH, VADV, MFMA>& lds, double* Tc = nullptr) {
   using namespace np8;
+  static_assert(!STEPS || (!VADV && !RELOAD_T && !BATCH), "step loop: plain Lagrangian form");
+  static_assert(!CARRY_IN || STEPS, "CARRY_IN: step loop only");
+  auto wg_sync = [] {
+    if constexpr (STEPS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // not the previous call's stores
+    else __syncthreads();
+  };
   constexpr int WAVES = NLEV / TPW;
   constexpr int THREADS = WAVES * 64;
   constexpr int BLK = NLEV * PP;
@@ -49,15 +75,15 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   static_assert(!VADV || !RELOAD_T, "Eulerian branch keeps T in registers");
   static_assert(!MFMA || (!BATCH && !COEF_LDS), "MFMA form: no LDS tile, Dvv slices are per-lane MFMA operands");
 
-  __shared__ __attribute__((aligned(16))) double s_dvvT[64];
-  __shared__ __attribute__((aligned(16))) double s_geo[G_SIZE];
-  constexpr int SLOTS = BATCH ? 5 : 1;  // LDS tile slots per wave (BATCH: p, T, Ephi, vcov1, vcov0)
-  __shared__ __attribute__((aligned(16))) double s_tile[MFMA ? 1 : WAVES * 64 * SLOTS];
-  __shared__ double s_park[3 * BLK + (VADV ? PP : 0)];  // dp, u, v of every level, [field][lev][pt] (+ a zero row for VADV)
-  __shared__ double s_tot_dp[WAVES * PP];   // per wave: sum of dp over its levels
-  __shared__ double s_tot_div[WAVES * PP];  // ... of divdp
-  __shared__ double s_tot_ht[WAVES * PP];   // ... of Rgas*T_v*dp/p
-  __shared__ double s_Thalo[VADV ? WAVES * 2 * PP : 1];  // VADV: T of each wave's first / last level
+  constexpr int SLOTS = BATCH ? 5 : 1;
+  double* const s_dvvT = lds.dvvT;
+  double* const s_geo = lds.geo;
+  double* const s_tile = lds.tile;
+  double* const s_park = lds.park;
+  double* const s_tot_dp = lds.tot_dp;
+  double* const s_tot_div = lds.tot_div;
+  double* const s_tot_ht = lds.tot_ht;
+  double* const s_Thalo = lds.Thalo;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -86,9 +112,15 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   auto load_n0 = [&](int r) {
     const unsigned off = r * PP + ulane;
     N0In x;
-    x.dp = stream_load<SNT>(dp_n0 + off);
-    x.uv = stream_load<SNT>(v_n0 + off);
-    x.T = stream_load<SNT && !RELOAD_T>(T_n0 + off);  // RELOAD_T: default policy, re-read from L2 in phase 3
+    if constexpr (CARRY_IN) {  // dp, u, v: where the previous call left them (read in phase 1); T: its registers
+      x.dp = 0.0;
+      x.uv = dbl2{0.0, 0.0};
+      x.T = 0.0;
+    } else {
+      x.dp = stream_load<SNT>(dp_n0 + off);
+      x.uv = stream_load<SNT>(v_n0 + off);
+      x.T = stream_load<SNT && !RELOAD_T>(T_n0 + off);  // RELOAD_T: default policy, re-read from L2 in phase 3
+    }
     x.q = MOIST ? stream_load<SNT>(Qdp + off) : 0.0;
     return x;
   };
@@ -96,7 +128,8 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
   N0In ring[PD];
 #pragma unroll
   for (int r = 0; r < PD; ++r) ring[r] = load_n0(r);
-  double T[RELOAD_T ? 1 : TPW], Tv[TPW];
+  double T_local[RELOAD_T ? 1 : TPW], Tv[TPW];
+  double* const T = STEPS ? Tc : T_local;
   double* const park_dp = s_park + lev0 * PP + lane;  // + r*PP; u, v follow at BLK strides
   // re-reads through a laundered LDS pointer: the compiler must not forward the parked values through registers
   const lds_cptr park_rd = lds_reread_ptr(park_dp);
@@ -113,7 +146,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     else src = k.Dinv + ie * PP * 4 + (idx - G_DINV);
     s_geo[idx] = stream_load<SNT>(src);
   }
-  __syncthreads();
+  wg_sync();
 
   MfmaCtx mc;
   if (MFMA) mc = make_mfma_ctx(k.Dvv, lane);
@@ -140,8 +173,14 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     double run_dp = 0.0, run_div = 0.0;
 #pragma unroll
     for (int r = 0; r < TPW; ++r) {
-      const N0In x = ring[r % PD];
+      N0In x = ring[r % PD];
       if (r + PD < TPW) ring[r % PD] = load_n0(r + PD);
+      if constexpr (CARRY_IN) {
+        x.dp = park_rd[r * PP];
+        x.uv.x = park_rd[BLK + r * PP];
+        x.uv.y = park_rd[2 * BLK + r * PP];
+        x.T = T[r];
+      }
       if (BATCH) {  // both contravariant components go to their slots, one LDS round trip
         const double vdp0 = x.uv.x * x.dp, vdp1 = x.uv.y * x.dp;                     // P:114-115
         const double gv0 = metdet * (Dinv.m00 * vdp0 + Dinv.m01 * vdp1);             // S:66-67
@@ -162,15 +201,17 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
       Tv[r] = MOIST ? x.T * (1.0 + k.rv_over_rd_m1 * (x.q * recip(x.dp))) : x.T;  // P:135,150-151
       run_dp += x.dp;
       run_div += divdp[r];
-      park_dp[r * PP] = x.dp;
-      park_dp[BLK + r * PP] = x.uv.x;
-      park_dp[2 * BLK + r * PP] = x.uv.y;
+      if constexpr (!CARRY_IN) {  // (carried: they are there already)
+        park_dp[r * PP] = x.dp;
+        park_dp[BLK + r * PP] = x.uv.x;
+        park_dp[2 * BLK + r * PP] = x.uv.y;
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     s_tot_dp[w * PP + pt] = run_dp;
     s_tot_div[w * PP + pt] = run_div;
   }
-  __syncthreads();
+  wg_sync();
 
   const dbl2* __restrict__ v_nm1 = reinterpret_cast<const dbl2*>(k.v + (ie * tl + k.nm1) * BLK * 2) + wbase;
   const double* __restrict__ T_nm1 = k.T + (ie * tl + k.nm1) * BLK + wbase;
@@ -233,7 +274,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
 
   double l_eta_last = 0.0;
   if (tid < PP) l_eta_last = eta_last[tid];
-  __syncthreads();
+  wg_sync();
 
   // ---- phase 3: level-local tendencies and update, top level of the wave first ----------
   double below = 0.0;  // hydrostatic sum over the waves below this one, bottom-up (P:293,302)
@@ -265,7 +306,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     const double phi = (phis + (below + (wave_ht - run_ht))) + 0.5 * ht;  // P:303,309
 
     const M22 Dm = load_m22(geo + G_D, pt);
-    const double Ephi = 0.5 * (ur * ur + vr * vr) + phi + cur.pec;     // P:196
+    const double Ephi = 0.5 * dot2(ur, ur, vr, vr) + phi + cur.pec;    // P:196
     double gp0, gp1, gT0, gT1, gE0, gE1, vort;
     if (BATCH) {
       // all five fields of the level go to their LDS slots, then every contraction reads:
@@ -300,9 +341,9 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
       gradient_sphere<COEF_LDS>(c, lane, Dinv, rrearth, Tr, gT0, gT1);   // P:200
       gradient_sphere<COEF_LDS>(c, lane, Dinv, rrearth, Ephi, gE0, gE1); // P:213
     }
-    const double vgrad_p = ur * gp0 + vr * gp1;                        // P:111
+    const double vgrad_p = dot2(ur, gp0, vr, gp1);                     // P:111
     const double ckk = 0.5 * rp, ckl = rp;                             // P:333-334
-    const double om = vgrad_p * rp - ckl * suml - ckk * divdp[r];      // P:325,336,348
+    const double om = __builtin_fma(-ckk, divdp[r], __builtin_fma(vgrad_p, rp, -(ckl * suml)));  // P:325,336,348
     double eta_lo = 0.0, eta_hi = 0.0, T_vadv = 0.0, u_vadv = 0.0, v_vadv = 0.0;
     if (VADV) {
       const int lev = lev0 + r;  // wave-uniform: hybi comes through scalar loads
@@ -326,7 +367,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
       v_vadv = facp * (v_dn - vr) + facm * (vr - v_up);
     }
     suml += divdp[r];                                                  // P:339
-    const double vgrad_T = ur * gT0 + vr * gT1;                        // P:209
+    const double vgrad_T = dot2(ur, gT0, vr, gT1);                     // P:209
     const double gpterm = Tv[r] * rp;                                  // P:219
     const double glnps1 = k.Rgas * gpterm * gp0;                       // P:221
     const double glnps2 = k.Rgas * gpterm * gp1;                       // P:222
@@ -344,7 +385,8 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     vo.x = spheremp * (cur.vnm1.x + k.dt2 * vtens1);                   // P:251
     vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);                   // P:252
     stream_store<SNT>(v_np1 + off, vo);
-    stream_store<SNT>(T_np1 + off, spheremp * (cur.Tnm1 + k.dt2 * ttens));       // P:253
+    const double T_new = spheremp * (cur.Tnm1 + k.dt2 * ttens);       // P:253
+    stream_store<SNT>(T_np1 + off, T_new);
     const double dp_new = VADV ? spheremp * (cur.dpnm1 - k.dt2 * (divdp[r] + eta_hi - eta_lo))  // X:515-517
                                : spheremp * (cur.dpnm1 - k.dt2 * divdp[r]);                     // P:254
     debug_check_dp3d(dp_new);  // CaarFunctor.hpp:82-97 check_dp3d (-DCAAR_DEBUG builds only)
@@ -356,9 +398,73 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
     vn.y = cur.vn0.y + k.eta_ave_w * (vr * dpr);                       // P:118
     stream_store<SNT>(vn0 + off, vn);
     stream_store<SNT>(eta + off, cur.eta + (VADV ? k.eta_ave_w * eta_lo : eta_zero));  // P:172, X:271-272
+    if constexpr (STEPS) {  // the state just stored at np1 is the next call's n0: it replaces this level's n0 state
+      park_dp[r * PP] = dp_new;
+      park_dp[BLK + r * PP] = vo.x;
+      park_dp[2 * BLK + r * PP] = vo.y;
+      T[r] = T_new;
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   if (tid < PP) eta_last[tid] = l_eta_last + eta_zero;                 // P:181
+}
+
+template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T, bool BATCH, bool VADV = false, bool MFMA = false, int LA = 1>
+__global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const KernelArgs k) {
+  __shared__ Np8Lds<NLEV, TPW, BATCH, VADV, MFMA> lds;
+  caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, COEF_LDS, RELOAD_T, BATCH, VADV, MFMA, LA>(k, lds);
+}
+
+// caar_run_steps / caar_launch_steps as ONE launch for NP=8 (the MFMA form; see caar_np4_steps.hip): every
+// workgroup makes all nsteps calls for its element.  With rotating, distinct time levels the first call loads everything
+// and every later call finds dp3d, u, v at n0 in the LDS park and T in registers, where the previous call left its np1
+// results; default cache policy, so that what is re-read (nm1 state, accumulators) is still on chip.  Bit-identical to
+// nsteps single launches.
+template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, int LA>
+__global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_steps_kernel(const KernelArgs k0, int nsteps, int rotate) {
+  __shared__ Np8Lds<NLEV, TPW, false, false, true> lds;
+  if (element_of_block(k0, blockIdx.x) < 0) return;
+  int n0 = k0.n0, np1 = k0.np1, nm1 = k0.nm1;
+  double Tc[TPW];  // T at n0 of this wave's levels, handed from call to call
+  const bool steady = rotate && n0 != np1 && n0 != nm1 && np1 != nm1;  // uniform
+  auto rotate_levels = [&] {  // TestData::update_time_levels
+    const int t = np1;
+    np1 = nm1;
+    nm1 = n0;
+    n0 = t;
+  };
+  auto args = [&] {
+    KernelArgs k = reload_args();
+    k.n0 = n0;
+    k.np1 = np1;
+    k.nm1 = nm1;
+    return k;
+  };
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  if (steady) {
+    caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, false>(args(), lds, Tc);
+    for (int s = 1; s < nsteps; ++s) {
+      rotate_levels();
+      lds_barrier();  // the next call re-stages the metric terms and re-uses the tile totals: everybody is done with them
+      caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, true>(args(), lds, Tc);
+    }
+  } else {
+    for (int s = 0; s < nsteps; ++s) {
+      caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, false>(args(), lds, Tc);
+      if (rotate) rotate_levels();
+      lds_barrier();
+    }
+  }
+}
+
+template <int NLEV, int TPW, int MINW, bool SNT, int LA>
+static hipError_t launch_np8_steps(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t stream) {
+  constexpr int THREADS = NLEV / TPW * 64;
+  if (k.vadv) return hipErrorNotSupported;
+  const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
+  if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np8_steps_kernel<NLEV, TPW, MINW, true, SNT, LA>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
+  else hipLaunchKernelGGL((caar_np8_steps_kernel<NLEV, TPW, MINW, false, SNT, LA>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
+  return hipGetLastError();
 }
 
 template <int NLEV, int TPW, int MINW, bool NT, bool COEF_LDS = false, bool RELOAD_T = false, bool BATCH = false, bool MFMA = false, int LA = 1>
@@ -381,8 +487,8 @@ static hipError_t launch_np8(const KernelArgs& k, int num_elems, hipStream_t str
 
 // (non-const on purpose, see caar_np4.hip)
 KernelVariant kNp8Nlev72[] = {
-    {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, true, 2>", "8 waves x 9 levels, nt, MFMA contractions, update-phase inputs requested two levels ahead", launch_np8<72, 9, 1, true, false, false, false, true, 2>, true},
-    {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, true, 1>", "8 waves x 9 levels, nt, Dvv contractions on v_mfma_f64_4x4x4 (lane = MFMA result layout, no LDS tile)", launch_np8<72, 9, 1, true, false, false, false, true>},
+    {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, true, 2>", "8 waves x 9 levels, nt, MFMA contractions, update-phase inputs requested two levels ahead", launch_np8<72, 9, 1, true, false, false, false, true, 2>, true, launch_np8_steps<72, 9, 1, false, 2>},
+    {"caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, true, 1>", "8 waves x 9 levels, nt, Dvv contractions on v_mfma_f64_4x4x4 (lane = MFMA result layout, no LDS tile)", launch_np8<72, 9, 1, true, false, false, false, true>, false, launch_np8_steps<72, 9, 1, true, 1>},
     {"caar_np8_kernel<72, 9, 1, true, true, true, false, false, false, false, 1>", "8 waves x 9 levels, nt, Dvv slices re-read from LDS", launch_np8<72, 9, 1, true, true, false, false>},
     {"caar_np8_kernel<72, 9, 1, true, false, true, false, false, false, false, 1>", "8 waves x 9 levels, default cache policy", launch_np8<72, 9, 1, false, true, false, false>},
     {"caar_np8_kernel<72, 12, 1, true, true, false, false, false, false, true, 1>", "6 waves x 12 levels, nt, MFMA contractions", launch_np8<72, 12, 1, true, false, false, false, true>},

@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "caar_kernel_args.h"
+
 namespace caar {
 
 namespace np8 {
@@ -93,15 +95,15 @@ __device__ __forceinline__ void gradient_sphere(const Ctx& c, int lane, const M2
   put_tile(c, lane, s);
   const double v1 = d_da_tile<COEF_LDS>(c) * rrearth;
   const double v2 = d_db_tile<COEF_LDS>(c) * rrearth;
-  g0 = Dinv.m00 * v1 + Dinv.m10 * v2;
-  g1 = Dinv.m01 * v1 + Dinv.m11 * v2;
+  g0 = dot2(Dinv.m00, v1, Dinv.m10, v2);
+  g1 = dot2(Dinv.m01, v1, Dinv.m11, v2);
 }
 // divergence_sphere, S:50-89
 template <bool COEF_LDS = false>
 __device__ __forceinline__ double divergence_sphere(const Ctx& c, int lane, const M22& Dinv, double metdet,
                                                     double rmetdet, double rrearth, double u, double v) {
-  const double gv0 = metdet * (Dinv.m00 * u + Dinv.m01 * v);
-  const double gv1 = metdet * (Dinv.m10 * u + Dinv.m11 * v);
+  const double gv0 = metdet * dot2(Dinv.m00, u, Dinv.m01, v);
+  const double gv1 = metdet * dot2(Dinv.m10, u, Dinv.m11, v);
   put_tile(c, lane, gv0);
   const double dudx = d_da_tile<COEF_LDS>(c);
   put_tile(c, lane, gv1);
@@ -112,8 +114,8 @@ __device__ __forceinline__ double divergence_sphere(const Ctx& c, int lane, cons
 template <bool COEF_LDS = false>
 __device__ __forceinline__ double vorticity_sphere(const Ctx& c, int lane, const M22& D, double rmetdet,
                                                    double rrearth, double u, double v) {
-  const double vc0 = D.m00 * u + D.m10 * v;
-  const double vc1 = D.m01 * u + D.m11 * v;
+  const double vc0 = dot2(D.m00, u, D.m10, v);
+  const double vc1 = dot2(D.m01, u, D.m11, v);
   put_tile(c, lane, vc1);
   const double dvdx = d_da_tile<COEF_LDS>(c);
   put_tile(c, lane, vc0);
@@ -190,19 +192,19 @@ __device__ __forceinline__ void gradient_sphere_mfma(const MfmaCtx& c, const M22
                                                      double& g0, double& g1) {
   const double v1 = mfma_d_da(c, s) * rrearth;
   const double v2 = mfma_d_db(c, s) * rrearth;
-  g0 = Dinv.m00 * v1 + Dinv.m10 * v2;
-  g1 = Dinv.m01 * v1 + Dinv.m11 * v2;
+  g0 = dot2(Dinv.m00, v1, Dinv.m10, v2);
+  g1 = dot2(Dinv.m01, v1, Dinv.m11, v2);
 }
 __device__ __forceinline__ double divergence_sphere_mfma(const MfmaCtx& c, const M22& Dinv, double metdet, double rmetdet,
                                                          double rrearth, double u, double v) {
-  const double gv0 = metdet * (Dinv.m00 * u + Dinv.m01 * v);
-  const double gv1 = metdet * (Dinv.m10 * u + Dinv.m11 * v);
+  const double gv0 = metdet * dot2(Dinv.m00, u, Dinv.m01, v);
+  const double gv1 = metdet * dot2(Dinv.m10, u, Dinv.m11, v);
   return (mfma_d_da(c, gv0) + mfma_d_db(c, gv1)) * rmetdet * rrearth;
 }
 __device__ __forceinline__ double vorticity_sphere_mfma(const MfmaCtx& c, const M22& D, double rmetdet, double rrearth,
                                                         double u, double v) {
-  const double vc0 = D.m00 * u + D.m10 * v;
-  const double vc1 = D.m01 * u + D.m11 * v;
+  const double vc0 = dot2(D.m00, u, D.m10, v);
+  const double vc1 = dot2(D.m01, u, D.m11, v);
   return (mfma_d_da(c, vc1) - mfma_d_db(c, vc0)) * rmetdet * rrearth;
 }
 
