@@ -52,6 +52,8 @@ def parse():
                     help="skip the short extra measurements of BASELINE.json configs[3] and [4]")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 --pmc child passes (the committed figure is used)")
+    ap.add_argument("--no-steps-leg", action="store_true",
+                    help="skip roofline.run_steps (the driver loop as one launch against single launches)")
     ap.add_argument("--no-interleaved", action="store_true",
                     help="skip the host-sequence measurements (roofline.interleaved: CAAR alternated with a tracer step / "
                          "a cache-evicting kernel, time levels rotating)")
@@ -163,6 +165,7 @@ def measure_config(np_, nlev, elems, steps, warmup):
             "element_updates_per_s": elems / (roof["kernel_ms"] * 1e-3), "achieved_GBs": roof["achieved"],
             "frac_of_hbm_peak": roof["frac"], "achieved_all_streaming_GBs": roof.get("achieved_all_streaming"),
             "algorithmic_bytes_per_element": roof["algorithmic_bytes_per_element"], "kernel": j["config"]["kernel"],
+            "run_steps": roof.get("run_steps"),
             "measured_in": "child process: " + " ".join(cmd[1:])}
 
 
@@ -412,6 +415,39 @@ def interleaved_sequences(tsa, torch, args, data, dev, stream, mine, steps):
     return out
 
 
+def run_steps_leg(tsa, torch, args, data, dev, stream, mine, calls=20):
+    """The driver loop itself (main.cpp:113-121 with update_time_levels): `calls` calls with rotating time levels through
+    caar_launch_steps — ONE launch where a step-loop kernel exists (every workgroup makes all the calls for its element, the
+    prognostic state carried from call to call in registers / LDS; bit-identical to single launches) — against
+    the same calls launched one by one.  Outside the timed region of `value`; the headline is per call and does not use it."""
+    lib = tsa.library().lib
+    saved = (data.control.n0, data.control.np1, data.control.nm1, data.control.dt2, data.constants.eta_ave_w)
+    data.control.dt2, data.constants.eta_ave_w = 1.0e-6, 0.0   # timing only: keeps hundreds of leap-frog steps finite
+
+    def timed(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            tsa.compute_and_apply_rhs_steps(data, calls, True, stream)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / (reps * calls)
+
+    out = {"calls_per_launch": calls, "one_launch_available": bool(lib.caar_has_fused_steps(args.np_, args.nlev, 0))}
+    try:
+        for label, fused in (("ms_per_call_single_launches", 0), ("ms_per_call_one_launch", 1)):
+            lib.caar_set_fused_steps(fused)
+            timed(2)
+            out[label] = min(timed(3) for _ in range(2))
+    finally:
+        lib.caar_set_fused_steps(1)
+        (data.control.n0, data.control.np1, data.control.nm1, data.control.dt2, data.constants.eta_ave_w) = saved
+    out["speedup"] = out["ms_per_call_single_launches"] / out["ms_per_call_one_launch"]
+    out["element_updates_per_s_one_launch"] = mine / (out["ms_per_call_one_launch"] * 1e-3)
+    out["algorithmic_GBs_one_launch"] = tsa.algorithmic_bytes(args.np_, args.nlev) * mine / (out["ms_per_call_one_launch"] * 1e-3) / 1e9
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -616,6 +652,9 @@ def main():
                 roof["traffic_source"] = TRAFFIC_SOURCE_LIVE
                 roof["traffic_detail"] = lt
                 roof["traffic_over_algorithmic"] = lt["bytes"] / per_launch_bytes
+        if world == 1 and not args.no_steps_leg:
+            # caar_run_steps / caar_launch_steps: not part of `value`
+            roof["run_steps"] = run_steps_leg(tsa, torch, args, data, dev, stream, mine)
         if world == 1 and not args.no_interleaved:
             seqs = interleaved_sequences(tsa, torch, args, data, dev, stream, mine, args.steps)
             roof["interleaved"] = seqs

@@ -53,6 +53,9 @@ def test_single_gpu_line_carries_the_contract_and_the_host_sequences():
         assert row["neighbour_ms"] > 0
         for label in ("default", "all_streaming"):
             assert row[label]["sequence_ms"] > row["neighbour_ms"] and row[label]["caar_ms"] > 0
+    rs = roof["run_steps"]   # the driver loop as one launch, beside the per-call headline
+    assert rs["one_launch_available"] and rs["calls_per_launch"] == 20
+    assert rs["ms_per_call_one_launch"] > 0 and rs["ms_per_call_single_launches"] > 0
     import shutil
     if shutil.which("rocprofv3"):   # HBM-side traffic from the counters, measured by the run itself
         assert roof["traffic_source"].startswith("measured in this run"), roof["traffic_source"]
