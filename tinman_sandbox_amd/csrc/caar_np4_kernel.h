@@ -115,9 +115,14 @@ struct Np4N0In {
 // CARRY_IN (compile time; STEPS only), what the previous call of the step loop handed over: bit 1 = `carry` holds this
 // call's n0 state (dp3d, u, v, T), 2 = lds.carry holds its nm1 state, 4 = lds.carry holds its tracer block (2 and 4 only
 // with CARRY_LDS).  Every STEPS call hands the same things on to the next one.
-template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW, int PARK = 0, bool STEPS = false, bool CARRY_LDS = false, int CARRY_IN = 0>
+template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW, int PARK = 0, bool STEPS = false, bool CARRY_LDS = false, int CARRY_IN = 0, int STORES = -1>
 __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW, PARK, CARRY_LDS>& lds,
-                                                 Np4N0In<TPW>* carry = nullptr) {
+                                                 Np4N0In<TPW>* carry = nullptr, int step_stores = 3) {
+  // step_stores (uniform; STEPS only; else all; STORES >= 0: the same as a compile-time constant, for the hot loop):
+  // bit 1 = store the np1 state (v, T, dp3d), bit 2 = store derived_phi.  The
+  // step loop leaves them out where a later call of the same launch overwrites them and nothing reads them in between:
+  // phi is never read (only the last call's survives); with the whole prognostic state carried on chip (CARRY_LDS) only
+  // the last three calls' np1 states are what single launches would leave in the three time levels.
   static_assert(!CARRY_LDS || STEPS, "CARRY_LDS: step loop only");
   static_assert(CARRY_IN == 0 || STEPS, "CARRY_IN: step loop only");
   static_assert(CARRY_LDS || (CARRY_IN & 6) == 0, "nm1 / tracer carry needs CARRY_LDS");
@@ -508,14 +513,16 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       dbl2 vo;
       vo.x = spheremp * (cur.vnm1.x + k.dt2 * vtens1);              // P:251
       vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);              // P:252
-      stream_store<SNT>(v_np1 + off, vo);
+      const int st_mask = STORES >= 0 ? STORES : step_stores;
+      const bool st_state = !STEPS || (st_mask & 1), st_phi = !STEPS || (st_mask & 2);
+      if (st_state) stream_store<SNT>(v_np1 + off, vo);
       const double T_new = spheremp * (cur.Tnm1 + k.dt2 * ttens);                     // P:253
-      stream_store<SNT>(T_np1 + off, T_new);
+      if (st_state) stream_store<SNT>(T_np1 + off, T_new);
       const double dp_new = VADV ? spheremp * (cur.dpnm1 - k.dt2 * (divdp_r + eta_hi - eta_lo))   // X:515-517
                                  : spheremp * (cur.dpnm1 - k.dt2 * divdp_r);                       // P:254
       debug_check_dp3d(dp_new);  // CaarFunctor.hpp:82-97 check_dp3d (-DCAAR_DEBUG builds only)
-      stream_store<SNT>(dp_np1 + off, dp_new);
-      stream_store<SNT>(phi_out + off, phi);                                        // P:294,303,309
+      if (st_state) stream_store<SNT>(dp_np1 + off, dp_new);
+      if (st_phi) stream_store<SNT>(phi_out + off, phi);                            // P:294,303,309
       stream_store<ANT>(omega_p + off, cur.om + k.eta_ave_w * om);                  // P:173
       dbl2 vn;
       vn.x = cur.vn0.x + k.eta_ave_w * (u_r * dp[r]);               // P:117

@@ -39,16 +39,36 @@ __device__ __forceinline__ void np4_step_loop(const KernelArgs& k0, int nsteps, 
     k.nm1 = nm1;
     return k;
   };
+  // Stores nothing ever reads: derived_phi is overwritten by every call (only the last one's survives), and with the whole
+  // prognostic state travelling on chip (CARRY_LDS) a call's np1 state is read from memory by no later call of the launch
+  // — the three time levels must hold what the LAST THREE calls wrote, as after single launches.  The store set is a
+  // compile-time property of the steady body (a run-time test around the stores costs 30-60 spilled VGPRs): calls
+  // 1 .. nsteps-4 store neither, calls nsteps-3 .. nsteps-2 the state, the last call both.
   if (steady) {
-    caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0>(args(), lds, &carry);
-    for (int s = 1; s < nsteps; ++s) {
+    const int first_mask = ((!CARRY_LDS || nsteps <= 3) ? 1 : 0) | (nsteps == 1 ? 2 : 0);
+    caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0>(args(), lds, &carry, first_mask);
+    constexpr int CIN = CARRY_LDS ? 7 : 1;
+    int s = 1;
+    if constexpr (CARRY_LDS) {
+      for (; s < nsteps - 3; ++s) {
+        rotate_levels();
+        wg_barrier<true>();  // the next call re-stages Dvv and the metric terms in LDS: everybody is done reading them
+        caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 0>(args(), lds, &carry);
+      }
+    }
+    for (; s < nsteps - 1; ++s) {
       rotate_levels();
-      wg_barrier<true>();  // the next call re-stages Dvv and the metric terms in LDS: everybody is done reading them
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CARRY_LDS ? 7 : 1>(args(), lds, &carry);
+      wg_barrier<true>();
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 1>(args(), lds, &carry);
+    }
+    if (s < nsteps) {
+      rotate_levels();
+      wg_barrier<true>();
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 3>(args(), lds, &carry);
     }
   } else {
-    for (int s = 0; s < nsteps; ++s) {
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0>(args(), lds, &carry);
+    for (int s = 0; s < nsteps; ++s) {  // (no carry: every call stores everything except a phi that will be overwritten)
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0>(args(), lds, &carry, 1 | (s == nsteps - 1 ? 2 : 0));
       if (rotate) rotate_levels();
       wg_barrier<true>();
     }
@@ -70,15 +90,15 @@ __global__ __launch_bounds__((NLEV_T + 3) / 4 / TPW * 64, MINW) void caar_np4_st
   }
 }
 
-template <int NLEV, int TPW, int MINW, int POL, int PF, int PARK>
+template <int NLEV, int TPW, int MINW, int POL, int PF, int PARK, bool CARRY_LDS = (NLEV <= 72)>
 static hipError_t launch_np4_steps(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t stream) {
   constexpr int THREADS = (NLEV + 3) / 4 / TPW * 64;
   if (k.vadv) return hipErrorNotSupported;  // the Eulerian form steps through the graph of single launches
   const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
   if (k.qn0 >= 0)
-    hipLaunchKernelGGL((caar_np4_steps_kernel<NLEV, TPW, MINW, true, POL, PF, PARK, (NLEV <= 72)>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
+    hipLaunchKernelGGL((caar_np4_steps_kernel<NLEV, TPW, MINW, true, POL, PF, PARK, CARRY_LDS>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
   else
-    hipLaunchKernelGGL((caar_np4_steps_kernel<NLEV, TPW, MINW, false, POL, PF, PARK, (NLEV <= 72)>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
+    hipLaunchKernelGGL((caar_np4_steps_kernel<NLEV, TPW, MINW, false, POL, PF, PARK, CARRY_LDS>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
   return hipGetLastError();
 }
 
@@ -94,7 +114,6 @@ CAAR_STEPS(128, 8, 2, 2, 0, 27)
 CAAR_STEPS(128, 8, 2, 1, 0, 27)
 CAAR_STEPS(128, 8, 2, 0, 0, 27)
 #undef CAAR_STEPS
-
 // What the default variants use.  From the second call on a call's inputs are the previous call's outputs: n0 state in
 // registers, (NLEV=72) nm1 state and tracer block in LDS, the rest still on chip if the accesses use the DEFAULT cache
 // policy — the opposite of what a single call wants.  NLEV=72: default policy at every size (0.221 ms per call at 10 000
@@ -103,8 +122,12 @@ CAAR_STEPS(128, 8, 2, 0, 0, 27)
 hipError_t launch_np4_steps_72_auto(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) {
   return launch_np4_steps_72_0(k, num_elems, nsteps, rotate, s);
 }
+// NLEV=128: ONE workgroup per CU, 8 waves x 4 tiles, with the room that leaves in LDS (96 KB) used to carry the nm1 state
+// and the tracer block like NLEV=72 does: 0.356 ms per call at 12 500 elements against 0.515 for the two-workgroup 4 x 8
+// shape, whose LDS is full of parked scan results and which therefore reads nm1 from cache
+// (profiles/r03/steps_bench_128_8x4.log).  Default cache policy.
 hipError_t launch_np4_steps_128_auto(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) {
-  return num_elems >= 3700 ? launch_np4_steps_128_0(k, num_elems, nsteps, rotate, s) : launch_np4_steps_128_2(k, num_elems, nsteps, rotate, s);
+  return launch_np4_steps<128, 4, 2, 0, 0, 0, true>(k, num_elems, nsteps, rotate, s);
 }
 
 #ifdef CAAR_DEBUG

@@ -60,7 +60,8 @@ struct Np8Lds {
 // loaded (every lane reads and writes only its own points, so what it stored is what it would load).
 template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T, bool BATCH, bool VADV = false, bool MFMA = false, int LA = 1,
           bool STEPS = false, bool CARRY_IN = false>
-__device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLEV, TPW, BATCH, VADV, MFMA>& lds, double* Tc = nullptr) {
+__device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLEV, TPW, BATCH, VADV, MFMA>& lds, double* Tc = nullptr,
+                                                 bool store_phi = true /* STEPS: false where a later call overwrites it */) {
   using namespace np8;
   static_assert(!STEPS || (!VADV && !RELOAD_T && !BATCH), "step loop: plain Lagrangian form");
   static_assert(!CARRY_IN || STEPS, "CARRY_IN: step loop only");
@@ -391,7 +392,7 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
                                : spheremp * (cur.dpnm1 - k.dt2 * divdp[r]);                     // P:254
     debug_check_dp3d(dp_new);  // CaarFunctor.hpp:82-97 check_dp3d (-DCAAR_DEBUG builds only)
     stream_store<SNT>(dp_np1 + off, dp_new);
-    stream_store<SNT>(phi_out + off, phi);
+    if (!STEPS || store_phi) stream_store<SNT>(phi_out + off, phi);
     stream_store<SNT>(omega_p + off, cur.om + k.eta_ave_w * om);                 // P:173
     dbl2 vn;
     vn.x = cur.vn0.x + k.eta_ave_w * (ur * dpr);                       // P:117
@@ -442,15 +443,15 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_steps_kernel(c
   };
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   if (steady) {
-    caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, false>(args(), lds, Tc);
+    caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, false>(args(), lds, Tc, nsteps == 1);
     for (int s = 1; s < nsteps; ++s) {
       rotate_levels();
       lds_barrier();  // the next call re-stages the metric terms and re-uses the tile totals: everybody is done with them
-      caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, true>(args(), lds, Tc);
+      caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, true>(args(), lds, Tc, s == nsteps - 1);
     }
   } else {
     for (int s = 0; s < nsteps; ++s) {
-      caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, false>(args(), lds, Tc);
+      caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, false>(args(), lds, Tc, s == nsteps - 1);
       if (rotate) rotate_levels();
       lds_barrier();
     }
