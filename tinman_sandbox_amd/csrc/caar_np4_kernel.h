@@ -70,7 +70,7 @@ enum { G_FCOR = 0, G_SPHEREMP = 16, G_METDET = 32, G_RMETDET = 48, G_PHIS = 64, 
 // The workgroup's LDS, declared ONCE in the kernel and shared by the code paths instantiated inside it (the
 // hybrid cache policy compiles the element body twice; as function-local __shared__ arrays every buffer
 // existed twice: 17.4 KB instead of 8.7 KB at NLEV=72).
-template <int NLEV_T, int TPW, bool PERSIST, bool VADV, int DYNW, int PARK = 0, bool CARRY_LDS = false>
+template <int NLEV_T, int TPW, bool PERSIST, bool VADV, int DYNW, int PARK = 0, int CARRY_LDS = 0>
 struct Np4Lds {
   static constexpr int PP = 16;
   static constexpr int NT_MAX = NLEV_T == 0 ? DYNW * TPW : (NLEV_T + 3) / 4;
@@ -89,9 +89,12 @@ struct Np4Lds {
   // u, v, T are re-read from `col` in the last phase instead of staying in registers
   static constexpr int NPARK = (PARK & 1) + ((PARK >> 1) & 1) + ((PARK >> 2) & 1) + ((PARK >> 3) & 1) + ((PARK >> 4) & 1);
   double park[NPARK ? NPARK : 1][NPARK ? NT_MAX * 64 : 1];
-  // CARRY_LDS (step loop): what the NEXT call will read as u, v, T, dp3d at nm1 (= this call's n0 state) and the tracer
-  // block, handed from call to call in LDS ([slot][tile * 64 + lane]; each lane re-reads only what it wrote)
-  double carry[CARRY_LDS ? 5 : 1][CARRY_LDS ? NT_MAX * 64 : 1];
+  // CARRY_LDS (step loop) >= 1: what the NEXT call will read as u, v, T, dp3d at nm1 (= this call's n0 state; slots 0-3) and
+  // the tracer block (4), handed from call to call in LDS ([slot][tile * 64 + lane]; each lane re-reads only what it wrote);
+  // 2: the accumulators as well — vn0 (5, 6), omega_p (7), eta_dot_dpdn (8) — and pecnd (9): a steady call then touches no
+  // element array in memory at all
+  static constexpr int NCARRY = CARRY_LDS >= 2 ? 10 : (CARRY_LDS ? 5 : 1);
+  double carry[NCARRY][CARRY_LDS ? NT_MAX * 64 : 1];
 };
 
 // PARK: the five per-point values that live from the scans to the last phase (p, divdp prefix, hydrostatic in-tile suffix,
@@ -114,8 +117,9 @@ struct Np4N0In {
 // previous step's stores.
 // CARRY_IN (compile time; STEPS only), what the previous call of the step loop handed over: bit 1 = `carry` holds this
 // call's n0 state (dp3d, u, v, T), 2 = lds.carry holds its nm1 state, 4 = lds.carry holds its tracer block (2 and 4 only
-// with CARRY_LDS).  Every STEPS call hands the same things on to the next one.
-template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW, int PARK = 0, bool STEPS = false, bool CARRY_LDS = false, int CARRY_IN = 0, int STORES = -1>
+// with CARRY_LDS), 8 = lds.carry holds the accumulators and pecnd, and the metric terms are still staged (CARRY_LDS == 2).
+// Every STEPS call hands the same things on to the next one.
+template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW, int PARK = 0, bool STEPS = false, int CARRY_LDS = 0, int CARRY_IN = 0, int STORES = -1>
 __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW, PARK, CARRY_LDS>& lds,
                                                  Np4N0In<TPW>* carry = nullptr, int step_stores = 3) {
   // step_stores (uniform; STEPS only; else all; STORES >= 0: the same as a compile-time constant, for the hot loop):
@@ -126,6 +130,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   static_assert(!CARRY_LDS || STEPS, "CARRY_LDS: step loop only");
   static_assert(CARRY_IN == 0 || STEPS, "CARRY_IN: step loop only");
   static_assert(CARRY_LDS || (CARRY_IN & 6) == 0, "nm1 / tracer carry needs CARRY_LDS");
+  static_assert(CARRY_LDS >= 2 || (CARRY_IN & 8) == 0, "accumulator carry needs CARRY_LDS == 2");
   constexpr int carry_flags = CARRY_IN;
   constexpr bool carry_valid = STEPS && (CARRY_IN & 1);
   constexpr int PP = 16;               // GLL points per level
@@ -294,10 +299,20 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         x.Tnm1 = stream_load<SNT>(T_nm1 + off);
         x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
       }
-      x.vn0 = stream_load<ANT>(vn0 + off);
-      x.om = stream_load<ANT>(omega_p + off);
-      x.pec = stream_load<SNT>(pecnd + off);
-      x.eta = stream_load<ANT>(eta + off);
+      if (CARRY_LDS >= 2 && (carry_flags & 8)) {  // the previous call left the accumulators (and pecnd) in LDS
+        const lds_cptr ca = lds_reread_ptr(&lds.carry[CARRY_LDS >= 2 ? 5 : 0][0] + (w * TPW + r) * 64 + lane);
+        constexpr int Q = NT_MAX * 64;
+        x.vn0.x = ca[0];
+        x.vn0.y = ca[Q];
+        x.om = ca[2 * Q];
+        x.eta = ca[3 * Q];
+        x.pec = ca[4 * Q];
+      } else {
+        x.vn0 = stream_load<ANT>(vn0 + off);
+        x.om = stream_load<ANT>(omega_p + off);
+        x.pec = stream_load<SNT>(pecnd + off);
+        x.eta = stream_load<ANT>(eta + off);
+      }
       return x;
     };
     // PF: when the update-phase inputs are requested: 2 = right behind the n0 loads,
@@ -312,7 +327,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     // previous element's last phase, ahead of its stores)
     if (PERSIST) {
       if (tid < G_SIZE) s_geo[tid] = geo_reg;
-    } else {
+    } else if (!(carry_flags & 8)) {  // (step loop, same element: the metric terms of the previous call are still there)
       for (int idx = tid; idx < G_SIZE; idx += THREADS) s_geo[idx] = stream_load<SNT>(geo_src(ie, idx));
     }
     wg_barrier<PERSIST || STEPS>();  // also fences the previous element's last reads of the tile totals
@@ -515,6 +530,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);              // P:252
       const int st_mask = STORES >= 0 ? STORES : step_stores;
       const bool st_state = !STEPS || (st_mask & 1), st_phi = !STEPS || (st_mask & 2);
+      const bool st_acc = CARRY_LDS < 2 || (st_mask & 4);  // accumulators carried in LDS: only the last call's reach memory
       if (st_state) stream_store<SNT>(v_np1 + off, vo);
       const double T_new = spheremp * (cur.Tnm1 + k.dt2 * ttens);                     // P:253
       if (st_state) stream_store<SNT>(T_np1 + off, T_new);
@@ -523,18 +539,27 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       debug_check_dp3d(dp_new);  // CaarFunctor.hpp:82-97 check_dp3d (-DCAAR_DEBUG builds only)
       if (st_state) stream_store<SNT>(dp_np1 + off, dp_new);
       if (st_phi) stream_store<SNT>(phi_out + off, phi);                            // P:294,303,309
-      stream_store<ANT>(omega_p + off, cur.om + k.eta_ave_w * om);                  // P:173
+      const double om_new = cur.om + k.eta_ave_w * om;                              // P:173
+      if (st_acc) stream_store<ANT>(omega_p + off, om_new);
       dbl2 vn;
       vn.x = cur.vn0.x + k.eta_ave_w * (u_r * dp[r]);               // P:117
       vn.y = cur.vn0.y + k.eta_ave_w * (v_r * dp[r]);               // P:118
-      stream_store<ANT>(vn0 + off, vn);
+      if (st_acc) stream_store<ANT>(vn0 + off, vn);
       {
         const double e_new = cur.eta + (VADV ? k.eta_ave_w * eta_lo : eta_zero);  // P:172, X:271-272
         // ETA_COND: the update adds eta_ave_w * 0 (vertically Lagrangian), so the stored value
         // differs from the loaded one only for -0.0 or a non-finite eta_ave_w; storing only
         // then keeps the array bit-identical to the reference's and drops the write traffic.
-        if (!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(cur.eta))
+        if ((!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(cur.eta)) && st_acc)
           stream_store<ANT>(eta + off, e_new);
+        if constexpr (CARRY_LDS >= 2) {
+          constexpr int A = CARRY_LDS >= 2 ? 5 : 0;
+          lds.carry[A][t * 64 + lane] = vn.x;
+          lds.carry[A + 1][t * 64 + lane] = vn.y;
+          lds.carry[A + 2][t * 64 + lane] = om_new;
+          lds.carry[A + 3][t * 64 + lane] = e_new;
+          if (!(carry_flags & 8)) lds.carry[A + 4][t * 64 + lane] = cur.pec;  // (first call; pecnd never changes)
+        }
       }
       if constexpr (CARRY_LDS) {  // this call's n0 state is the next call's nm1
         lds.carry[0][t * 64 + lane] = u_r;

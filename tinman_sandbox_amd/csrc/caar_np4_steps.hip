@@ -20,7 +20,7 @@ namespace caar {
 // state from registers and (CARRY_LDS) its nm1 state and tracer block from LDS — two instantiations of the body, the
 // steady one with no n0 / nm1 / Qdp loads at all.  Without rotation, or with aliased time levels, every call loads
 // what it reads (what a lane stored is what it loads: same results, no carry).
-template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, int PARK, bool CARRY_LDS>
+template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, int PARK, int CARRY_LDS>
 __device__ __forceinline__ void np4_step_loop(const KernelArgs& k0, int nsteps, int rotate,
                                               Np4Lds<NLEV_T, TPW, false, false, 8, PARK, CARRY_LDS>& lds) {
   int n0 = k0.n0, np1 = k0.np1, nm1 = k0.nm1;
@@ -45,9 +45,9 @@ __device__ __forceinline__ void np4_step_loop(const KernelArgs& k0, int nsteps, 
   // compile-time property of the steady body (a run-time test around the stores costs 30-60 spilled VGPRs): calls
   // 1 .. nsteps-4 store neither, calls nsteps-3 .. nsteps-2 the state, the last call both.
   if (steady) {
-    const int first_mask = ((!CARRY_LDS || nsteps <= 3) ? 1 : 0) | (nsteps == 1 ? 2 : 0);
+    const int first_mask = ((!CARRY_LDS || nsteps <= 3) ? 1 : 0) | (nsteps == 1 ? 6 : 0);
     caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0>(args(), lds, &carry, first_mask);
-    constexpr int CIN = CARRY_LDS ? 7 : 1;
+    constexpr int CIN = CARRY_LDS >= 2 ? 15 : (CARRY_LDS ? 7 : 1);
     int s = 1;
     if constexpr (CARRY_LDS) {
       for (; s < nsteps - 3; ++s) {
@@ -64,11 +64,11 @@ __device__ __forceinline__ void np4_step_loop(const KernelArgs& k0, int nsteps, 
     if (s < nsteps) {
       rotate_levels();
       wg_barrier<true>();
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 3>(args(), lds, &carry);
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 7>(args(), lds, &carry);
     }
   } else {
     for (int s = 0; s < nsteps; ++s) {  // (no carry: every call stores everything except a phi that will be overwritten)
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0>(args(), lds, &carry, 1 | (s == nsteps - 1 ? 2 : 0));
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0>(args(), lds, &carry, 1 | 4 | (s == nsteps - 1 ? 2 : 0));
       if (rotate) rotate_levels();
       wg_barrier<true>();
     }
@@ -77,7 +77,7 @@ __device__ __forceinline__ void np4_step_loop(const KernelArgs& k0, int nsteps, 
 
 // CARRY_LDS: the nm1 state and the tracer block travel from call to call in LDS (NLEV=72: 46 KB more, two workgroups per CU
 // still fit; NLEV=128 has no room next to its parked scan results).
-template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, int PARK, bool CARRY_LDS>
+template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, int PARK, int CARRY_LDS>
 __global__ __launch_bounds__((NLEV_T + 3) / 4 / TPW * 64, MINW) void caar_np4_steps_kernel(const KernelArgs k0, int nsteps, int rotate) {
   __shared__ Np4Lds<NLEV_T, TPW, false, false, 8, PARK, CARRY_LDS> lds;
   const long long ie_s = element_of_block(k0, blockIdx.x);
@@ -90,7 +90,7 @@ __global__ __launch_bounds__((NLEV_T + 3) / 4 / TPW * 64, MINW) void caar_np4_st
   }
 }
 
-template <int NLEV, int TPW, int MINW, int POL, int PF, int PARK, bool CARRY_LDS = (NLEV <= 72)>
+template <int NLEV, int TPW, int MINW, int POL, int PF, int PARK, int CARRY_LDS = (NLEV <= 72 ? 1 : 0)>
 static hipError_t launch_np4_steps(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t stream) {
   constexpr int THREADS = (NLEV + 3) / 4 / TPW * 64;
   if (k.vadv) return hipErrorNotSupported;  // the Eulerian form steps through the graph of single launches
@@ -119,9 +119,21 @@ CAAR_STEPS(128, 8, 2, 0, 0, 27)
 // policy — the opposite of what a single call wants.  NLEV=72: default policy at every size (0.221 ms per call at 10 000
 // elements against 0.244 all-streaming and 0.322 for single launches; 23 us against 30 hybrid at 1 024).  NLEV=128 (no LDS
 // carry): hybrid is 3 % ahead below ~3 700 elements, equal above.  profiles/r03/steps_bench_72_final.log, _128_final.log.
+hipError_t launch_np4_steps_72_onchip(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s);
 hipError_t launch_np4_steps_72_auto(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) {
-  return launch_np4_steps_72_0(k, num_elems, nsteps, rotate, s);
+  // Up to ~2 elements per CU a call is bound by the latency of ONE element's step: everything on chip (one 6 x 3 workgroup
+  // per CU; 5.1 us per call at 64-256 elements against 7.3-7.7).  Beyond that two workgroups per CU, overlapping two
+  // elements, win (0.180 against 0.193 ms per call at 10 000 elements).  profiles/r03/steps_bench_72_onchip.log.
+  return num_elems <= 640 ? launch_np4_steps_72_onchip(k, num_elems, nsteps, rotate, s)
+                          : launch_np4_steps_72_0(k, num_elems, nsteps, rotate, s);
 }
+// NLEV=72 with EVERYTHING a call needs from its predecessor on chip (CARRY_LDS = 2: the accumulators and pecnd in LDS as
+// well, the metric terms left staged): one workgroup per CU, 6 waves x 3 tiles, 101 KB of LDS.  A steady call then touches
+// no element array in memory.
+hipError_t launch_np4_steps_72_onchip(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) {
+  return launch_np4_steps<72, 3, 2, 0, 0, 0, 2>(k, num_elems, nsteps, rotate, s);
+}
+
 // NLEV=128: ONE workgroup per CU, 8 waves x 4 tiles, with the room that leaves in LDS (96 KB) used to carry the nm1 state
 // and the tracer block like NLEV=72 does: 0.356 ms per call at 12 500 elements against 0.515 for the two-workgroup 4 x 8
 // shape, whose LDS is full of parked scan results and which therefore reads nm1 from cache
