@@ -61,6 +61,11 @@ module caar_mod
     integer(c_int) function caar_run(ctx, prm) bind(C, name="caar_run")
       import; type(c_ptr), value :: ctx; type(caar_params_t) :: prm
     end function
+    ! nsteps calls with update_time_levels between them (main.F90:201-210 with its rotation) as one launch: the caller
+    ! rotates its own np1 / nm1 / n0 nsteps times afterwards
+    integer(c_int) function caar_run_steps(ctx, prm, nsteps, rotate) bind(C, name="caar_run_steps")
+      import; type(c_ptr), value :: ctx; type(caar_params_t) :: prm; integer(c_int), value :: nsteps, rotate
+    end function
     integer(c_int) function caar_sync(ctx) bind(C, name="caar_sync")
       import; type(c_ptr), value :: ctx
     end function

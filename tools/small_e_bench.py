@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Latency regime: time per call for element counts far below what fills the chip
-(BASELINE configs[0] is 64 elements), plain stream launches vs one hipGraph of 20 calls."""
+(BASELINE configs[0] is 64 elements): plain stream launches, one hipGraph of 20 calls, and the 20 calls as ONE kernel
+launch with rotating time levels (caar_launch_steps)."""
 import os
 import sys
 
@@ -34,5 +35,15 @@ for E in (16, 64, 256, 1024, 4096):
     b.record()
     torch.cuda.synchronize()
     graph = a.elapsed_time(b) / 200
-    print("E=%5d  stream launches %.2f us/call (%.2f M updates/s) | hipGraph of 20 %.2f us/call (%.2f M updates/s)" % (
-        E, plain * 1e3, E / plain / 1e3, graph * 1e3, E / graph / 1e3), flush=True)
+    data.constants.eta_ave_w, data.control.dt2 = 0.0, 1e-6   # timing only: keeps hundreds of leap-frog steps finite
+    tsa.compute_and_apply_rhs_steps(data, 20, True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(10):
+        tsa.compute_and_apply_rhs_steps(data, 20, True)
+    b.record()
+    torch.cuda.synchronize()
+    loop = a.elapsed_time(b) / 200
+    print("E=%5d  stream launches %.2f us/call (%.2f M updates/s) | hipGraph of 20 %.2f us/call (%.2f M updates/s) | "
+          "one launch of 20 calls %.2f us/call (%.2f M updates/s)" % (
+              E, plain * 1e3, E / plain / 1e3, graph * 1e3, E / graph / 1e3, loop * 1e3, E / loop / 1e3), flush=True)
