@@ -20,8 +20,9 @@ import torch  # imported BEFORE the HIP library is loaded so both share one HIP 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CAAR_LIBRARY=debug loads the -DCAAR_DEBUG build (dp3d(np1) > 0 checked by the kernels, caar_debug_dp3d_violations)
-LIB_PATH = os.path.join(_HERE, "csrc", "libcaar_hip_debug.so" if os.environ.get("CAAR_LIBRARY", "") == "debug"
-                        else "libcaar_hip.so")
+LIB_PATH = os.path.join(_HERE, "csrc", {"debug": "libcaar_hip_debug.so"}.get(os.environ.get("CAAR_LIBRARY", ""), "libcaar_hip.so"))
+if os.environ.get("CAAR_LIBRARY_PATH"):  # an explicitly named build (A/B of compile-time choices)
+    LIB_PATH = os.environ["CAAR_LIBRARY_PATH"]
 
 # member order of Homme::Arrays (data_structures.hpp:18-44) == CaarArrays
 ARRAY_NAMES = (

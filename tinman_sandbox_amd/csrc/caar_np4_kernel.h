@@ -5,6 +5,8 @@
 #define CAAR_NP4_KERNEL_H
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "caar_kernel_args.h"
 #include "caar_np4_ops.h"
 
@@ -14,24 +16,41 @@ namespace caar {
 // Lanes l, l+16, l+32, l+48 hold levels 4t..4t+3 of one GLL point.
 __device__ __forceinline__ double shfl_abs(double x, int src_lane) { return __shfl(x, src_lane, 64); }
 
+// Lane -> (level inside the tile, GLL point).  CAAR_NP4_MFMA = 0 (default): lane = 16lev + 4a + b, the Dvv contractions
+// inside DPP rows.  1: lane = 16a + 4lev + b, the operand / result layout of v_mfma_f64_4x4x4 (caar_np4_ops.h "MFMA
+// form"): the contractions of the four levels of a tile are ONE matrix instruction each.  Either way a wave covers the
+// same 64 consecutive doubles of a field block; LSTEP is the lane distance between consecutive levels (the in-tile scans).
+// Measured A/B, two builds alternating on one box (profiles/r03/kbench_mfma_vs_dpp.log, steps_bench_72_mfma.log): the
+// MFMA form has ~14 fewer VGPRs and makes the step loop 12 % faster (0.161 against 0.180 ms per call at 10 000 elements:
+// that loop is close to VALU-bound), but the memory-bound single call 0.5-1 % SLOWER (82.6-82.7 % against 83.1-83.2 % with
+// the cache window, 74.3 against 75.2 % all-streaming: lanes of a wave address their 512 bytes in 32-byte groups instead
+// of in order).  The single call is the headline, and the step loop has to stay bit-identical to it, so the whole NP=4
+// family uses the DPP form; all 171 GPU tests pass with either.
+#ifndef CAAR_NP4_MFMA
+#define CAAR_NP4_MFMA 0
+#endif
+constexpr bool kNp4Mfma = CAAR_NP4_MFMA != 0;
+constexpr int LSTEP = kNp4Mfma ? 4 : 16;
+using Np4Ctx = std::conditional<kNp4Mfma, Mfma4Ctx, RowCoef>::type;
+
 // inclusive prefix (towards higher levels) and the matching exclusive value
 __device__ __forceinline__ void scan_down(double x, int lane, int sub, double& incl, double& excl) {
-  double t = shfl_abs(x, lane - 16);
+  double t = shfl_abs(x, lane - LSTEP);
   if (sub >= 1) x += t;
-  t = shfl_abs(x, lane - 32);
+  t = shfl_abs(x, lane - 2 * LSTEP);
   if (sub >= 2) x += t;
   incl = x;
-  t = shfl_abs(x, lane - 16);
+  t = shfl_abs(x, lane - LSTEP);
   excl = sub >= 1 ? t : 0.0;
 }
 // inclusive suffix (towards lower level index) and the matching exclusive value
 __device__ __forceinline__ void scan_up(double x, int lane, int sub, double& incl, double& excl) {
-  double t = shfl_abs(x, lane + 16);
+  double t = shfl_abs(x, lane + LSTEP);
   if (sub <= 2) x += t;
-  t = shfl_abs(x, lane + 32);
+  t = shfl_abs(x, lane + 2 * LSTEP);
   if (sub <= 1) x += t;
   incl = x;
-  t = shfl_abs(x, lane + 16);
+  t = shfl_abs(x, lane + LSTEP);
   excl = sub <= 2 ? t : 0.0;
 }
 
@@ -159,8 +178,8 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pt = lane & 15;
-  const int sub = lane >> 4;
+  const int pt = kNp4Mfma ? mfma4_point(lane) : (lane & 15);
+  const int sub = kNp4Mfma ? mfma4_level(lane) : (lane >> 4);
   const size_t tl = (size_t)k.timelevels;
   // RAGGED (NLEV not a multiple of 4): the rows of the last tile beyond level NLEV-1 are dead:
   // their loads are masked and return 0, they contribute 0 to the three integrals, and they
@@ -170,7 +189,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   // wave's first tile folded in: an SGPR pair) and is indexed by `r * 64 + ulane` with r
   // a compile-time tile number and ulane an UNSIGNED lane id, so each access is one
   // global_load/store with scalar base, one shared 32-bit lane offset and an immediate.
-  const unsigned ulane = lane;
+  const unsigned ulane = sub * 16 + pt;  // this lane's offset inside a tile of the layout [lev][a][b]
   const size_t wbase = (size_t)w * (TPW * 64);  // first point of this wave's tiles inside a field block
 
   long long ie_s = PERSIST ? (blockIdx.x < (unsigned)k.nelem ? (long long)k.nets + blockIdx.x : -1)
@@ -251,7 +270,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       }
     }
   }
-  RowCoef c;
+  Np4Ctx c;
   int par = 0;
   bool first = true;
 
@@ -333,7 +352,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     wg_barrier<PERSIST || STEPS>();  // also fences the previous element's last reads of the tile totals
 
     if (first) {
-      c = make_row_coef(s_dvv, lane);
+      make_np4_ctx(c, s_dvv, lane);
       first = false;
     }
     M22 Dinv;
@@ -361,9 +380,9 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         s_tot_div[t * PP + pt] = in_div;
       }
       if (VADV && live_row(r)) {
-        s_col[0][PP + t * 64 + lane] = T[r];
-        s_col[1][PP + t * 64 + lane] = u[r];
-        s_col[2][PP + t * 64 + lane] = v[r];
+        s_col[0][PP + t * 64 + ulane] = T[r];
+        s_col[1][PP + t * 64 + ulane] = u[r];
+        s_col[2][PP + t * 64 + ulane] = v[r];
       }
     }
     wg_barrier<PERSIST || STEPS>();
@@ -411,7 +430,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     }
     TileIn cur = PF ? pre[TPW - 1] : load_tile(TPW - 1);  // in flight across the barrier
     double l_eta_last = 0.0;
-    if (tid < PP) l_eta_last = eta_last[ulane];
+    if (tid < PP) l_eta_last = eta_last[tid];
     wg_barrier<PERSIST || STEPS>();
 
     // PERSIST: request the next element's n0 inputs now; they land while phase 3 computes
@@ -470,7 +489,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       // PARK bit 32 (Eulerian form only): u, v, T of this tile are re-read from the column copy phase 1 left in LDS
       double u_r, v_r, T_r;
       if constexpr (VADV && (PARK & 32)) {
-        const lds_cptr cc = lds_reread_ptr(&s_col[0][0] + PP + t * 64 + lane);
+        const lds_cptr cc = lds_reread_ptr(&s_col[0][0] + PP + t * 64 + ulane);
         constexpr int CS = sizeof(s_col[0]) / sizeof(double);
         T_r = cc[0];
         u_r = cc[CS];
@@ -511,7 +530,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         eta_hi = lev >= NLEV - 1 ? 0.0 : s_hybi[lev + 1] * sdot_sum - (suml_r + divdp_r);
         const double half_rdp = 0.5 * recip(dp[r]);                 // X:118
         const double facp = half_rdp * eta_hi, facm = half_rdp * eta_lo;   // CaarFunctor.hpp:526-527
-        const int ci = PP + t * 64 + lane;
+        const int ci = PP + t * 64 + ulane;
         // CaarFunctor.hpp:513-546 (the zero rows of s_col stand in for the missing one-sided terms)
         const double T_vadv = facp * (s_col[0][ci + PP] - T_r) + facm * (T_r - s_col[0][ci - PP]);
         const double u_vadv = facp * (s_col[1][ci + PP] - u_r) + facm * (u_r - s_col[1][ci - PP]);
@@ -582,7 +601,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     }
     if (tid < PP) {
       const double e_new = l_eta_last + eta_zero;                     // P:181
-      if (!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(l_eta_last)) eta_last[ulane] = e_new;
+      if (!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(l_eta_last)) eta_last[tid] = e_new;
     }
 
     if (!PERSIST || nxt_ie < 0) break;

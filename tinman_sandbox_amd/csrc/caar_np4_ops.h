@@ -131,5 +131,28 @@ __device__ __forceinline__ double mfma4_w_a(const Mfma4Ctx& c, double f) { retur
 // sum_k Dvv[b][k] f[a][k]
 __device__ __forceinline__ double mfma4_w_b(const Mfma4Ctx& c, double f) { return mfma4x4(__shfl(f, c.src_t, 64), c.d_lh); }
 
+// one name for both forms' coefficient set-up (the kernels pick the form at compile time)
+__device__ __forceinline__ void make_np4_ctx(RowCoef& c, const double* dvv, int lane) { c = make_row_coef(dvv, lane); }
+__device__ __forceinline__ void make_np4_ctx(Mfma4Ctx& c, const double* dvv, int lane) { c = make_mfma4_ctx(dvv, lane); }
+
+// the three operators of the path (S:9-129) on the MFMA contractions: the same formulas as the DPP forms above
+__device__ __forceinline__ void gradient_sphere(const Mfma4Ctx& c, const M22& Dinv, double rrearth, double s, double& g0, double& g1) {
+  const double v1 = mfma4_d_da(c, s) * rrearth;
+  const double v2 = mfma4_d_db(c, s) * rrearth;
+  g0 = dot2(Dinv.m00, v1, Dinv.m10, v2);
+  g1 = dot2(Dinv.m01, v1, Dinv.m11, v2);
+}
+__device__ __forceinline__ double divergence_sphere(const Mfma4Ctx& c, const M22& Dinv, double metdet, double rmetdet, double rrearth,
+                                                    double u, double v) {
+  const double gv0 = metdet * dot2(Dinv.m00, u, Dinv.m01, v);
+  const double gv1 = metdet * dot2(Dinv.m10, u, Dinv.m11, v);
+  return (mfma4_d_da(c, gv0) + mfma4_d_db(c, gv1)) * rmetdet * rrearth;
+}
+__device__ __forceinline__ double vorticity_sphere(const Mfma4Ctx& c, const M22& D, double rmetdet, double rrearth, double u, double v) {
+  const double vc0 = dot2(D.m00, u, D.m10, v);
+  const double vc1 = dot2(D.m01, u, D.m11, v);
+  return (mfma4_d_da(c, vc1) - mfma4_d_db(c, vc0)) * rmetdet * rrearth;
+}
+
 }  // namespace caar
 #endif
