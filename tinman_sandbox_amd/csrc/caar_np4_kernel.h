@@ -178,8 +178,8 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pt = kNp4Mfma ? mfma4_point(lane) : (lane & 15);
-  const int sub = kNp4Mfma ? mfma4_level(lane) : (lane >> 4);
+  const int pt = kNp4Mfma ? mfma4_point(lane) : lane & 15;
+  const int sub = kNp4Mfma ? mfma4_level(lane) : lane >> 4;
   const size_t tl = (size_t)k.timelevels;
   // RAGGED (NLEV not a multiple of 4): the rows of the last tile beyond level NLEV-1 are dead:
   // their loads are masked and return 0, they contribute 0 to the three integrals, and they
@@ -189,7 +189,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   // wave's first tile folded in: an SGPR pair) and is indexed by `r * 64 + ulane` with r
   // a compile-time tile number and ulane an UNSIGNED lane id, so each access is one
   // global_load/store with scalar base, one shared 32-bit lane offset and an immediate.
-  const unsigned ulane = sub * 16 + pt;  // this lane's offset inside a tile of the layout [lev][a][b]
+  const unsigned ulane = kNp4Mfma ? sub * 16 + pt : lane;  // this lane's offset inside a tile of the layout [lev][a][b]
   const size_t wbase = (size_t)w * (TPW * 64);  // first point of this wave's tiles inside a field block
 
   long long ie_s = PERSIST ? (blockIdx.x < (unsigned)k.nelem ? (long long)k.nets + blockIdx.x : -1)
@@ -306,13 +306,9 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       const unsigned off = r * 64 + ulane;
       TileIn x = {};
       if (!live_row(r)) return x;
-      if (CARRY_LDS && (carry_flags & 2)) {  // the previous call parked its n0 state: this call's nm1
-        const lds_cptr cn = lds_reread_ptr(&lds.carry[0][0] + (w * TPW + r) * 64 + lane);
-        constexpr int Q = NT_MAX * 64;
-        x.vnm1.x = cn[0];
-        x.vnm1.y = cn[Q];
-        x.Tnm1 = cn[2 * Q];
-        x.dpnm1 = cn[3 * Q];
+      if (CARRY_LDS && (carry_flags & 2)) {
+        // the previous call parked its n0 state (this call's nm1) in LDS: it is read where it is used, not a tile ahead
+        // (LDS latency needs no prefetch, and four values fewer are live per tile in flight)
       } else {
         x.vnm1 = stream_load<SNT>(v_nm1 + off);
         x.Tnm1 = stream_load<SNT>(T_nm1 + off);
@@ -430,7 +426,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     }
     TileIn cur = PF ? pre[TPW - 1] : load_tile(TPW - 1);  // in flight across the barrier
     double l_eta_last = 0.0;
-    if (tid < PP) l_eta_last = eta_last[tid];
+    if (tid < PP) l_eta_last = eta_last[kNp4Mfma ? (unsigned)tid : ulane];
     wg_barrier<PERSIST || STEPS>();
 
     // PERSIST: request the next element's n0 inputs now; they land while phase 3 computes
@@ -544,17 +540,27 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         cur = nxt;
         continue;
       }
+      dbl2 vnm1 = cur.vnm1;
+      double Tnm1 = cur.Tnm1, dpnm1 = cur.dpnm1;
+      if constexpr (CARRY_LDS && (carry_flags & 2)) {
+        const lds_cptr cn = lds_reread_ptr(&lds.carry[0][0] + t * 64 + lane);
+        constexpr int Q = NT_MAX * 64;
+        vnm1.x = cn[0];
+        vnm1.y = cn[Q];
+        Tnm1 = cn[2 * Q];
+        dpnm1 = cn[3 * Q];
+      }
       dbl2 vo;
-      vo.x = spheremp * (cur.vnm1.x + k.dt2 * vtens1);              // P:251
-      vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);              // P:252
+      vo.x = spheremp * (vnm1.x + k.dt2 * vtens1);                  // P:251
+      vo.y = spheremp * (vnm1.y + k.dt2 * vtens2);                  // P:252
       const int st_mask = STORES >= 0 ? STORES : step_stores;
       const bool st_state = !STEPS || (st_mask & 1), st_phi = !STEPS || (st_mask & 2);
       const bool st_acc = CARRY_LDS < 2 || (st_mask & 4);  // accumulators carried in LDS: only the last call's reach memory
       if (st_state) stream_store<SNT>(v_np1 + off, vo);
-      const double T_new = spheremp * (cur.Tnm1 + k.dt2 * ttens);                     // P:253
+      const double T_new = spheremp * (Tnm1 + k.dt2 * ttens);                         // P:253
       if (st_state) stream_store<SNT>(T_np1 + off, T_new);
-      const double dp_new = VADV ? spheremp * (cur.dpnm1 - k.dt2 * (divdp_r + eta_hi - eta_lo))   // X:515-517
-                                 : spheremp * (cur.dpnm1 - k.dt2 * divdp_r);                       // P:254
+      const double dp_new = VADV ? spheremp * (dpnm1 - k.dt2 * (divdp_r + eta_hi - eta_lo))   // X:515-517
+                                 : spheremp * (dpnm1 - k.dt2 * divdp_r);                       // P:254
       debug_check_dp3d(dp_new);  // CaarFunctor.hpp:82-97 check_dp3d (-DCAAR_DEBUG builds only)
       if (st_state) stream_store<SNT>(dp_np1 + off, dp_new);
       if (st_phi) stream_store<SNT>(phi_out + off, phi);                            // P:294,303,309
@@ -601,7 +607,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     }
     if (tid < PP) {
       const double e_new = l_eta_last + eta_zero;                     // P:181
-      if (!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(l_eta_last)) eta_last[tid] = e_new;
+      if (!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(l_eta_last)) eta_last[kNp4Mfma ? (unsigned)tid : ulane] = e_new;
     }
 
     if (!PERSIST || nxt_ie < 0) break;
