@@ -532,6 +532,38 @@ def test_launch_steps_without_a_step_loop_kernel_equals_single_calls(np_, nlev, 
                                    None) == -1   # nsteps < 1
 
 
+@pytest.mark.parametrize("np_,nlev,E", [(4, 72, 300), (4, 72, 900), (4, 128, 200), (8, 72, 60)])
+def test_long_step_loop_with_extra_tracers_and_time_levels(np_, nlev, E):
+    """25 calls in one launch on arrays with 3 tracer slots and 4 time levels (the reference's dimensions are compile-time
+    constants, config.h.in: QSIZE_D, NUM_TIME_LEVELS), second tracer slot, a sub-range of the elements — bitwise what 25
+    single launches leave (E = 300 / 900: both NLEV=72 step loops, the all-on-chip one and the two-workgroup one)."""
+    lib = tsa.library().lib
+    arrs = cases.hashed_arrays(np_, nlev, 4, seed=900 + np_ + nlev, qsize_d=3, timelevels=4)
+    reps = -(-E // 4)
+    arrs = {k: np.concatenate([v] * reps, axis=0)[:E].copy() for k, v in arrs.items()}
+    Dvv = cases.dvv_for(np_)
+    sc = po.default_scalars(nlev)
+    sc.update(dt2=1.0e-3, eta_ave_w=0.25, qn0=1, n0=3, np1=0, nm1=2, nets=5, nete=E - 7)
+    a = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    b = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")
+    try:
+        tsa.compute_and_apply_rhs_steps(a, 25, True)
+        lib.caar_set_fused_steps(0)
+        tsa.compute_and_apply_rhs_steps(b, 25, True)
+    finally:
+        lib.caar_set_fused_steps(1)
+    torch.cuda.synchronize()
+    for n in tsa.ARRAY_NAMES:
+        assert torch.equal(a.arrays[n], b.arrays[n]), n
+        assert torch.isfinite(a.arrays[n]).all(), n
+    # nothing outside [nets, nete) and no untouched time level / tracer slot changed
+    for n in tsa.caar.MUTATED:
+        assert np.array_equal(a.arrays[n][:5].cpu().numpy(), arrs[n][:5]), n
+        assert np.array_equal(a.arrays[n][E - 7:].cpu().numpy(), arrs[n][E - 7:]), n
+    assert np.array_equal(a.arrays["elem_state_T"][:, 1].cpu().numpy(), arrs["elem_state_T"][:, 1])   # level 1 is never used
+    assert np.array_equal(a.arrays["elem_state_Qdp"].cpu().numpy(), arrs["elem_state_Qdp"])
+
+
 def test_placement_arguments_are_validated():
     import ctypes as C
     from tinman_sandbox_amd import caar as m
