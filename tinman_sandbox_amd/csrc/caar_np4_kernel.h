@@ -111,8 +111,8 @@ struct Np4Lds {
   // CARRY_LDS (step loop) >= 1: what the NEXT call will read as u, v, T, dp3d at nm1 (= this call's n0 state; slots 0-3) and
   // the tracer block (4), handed from call to call in LDS ([slot][tile * 64 + lane]; each lane re-reads only what it wrote);
   // 2: the accumulators as well — vn0 (5, 6), omega_p (7), eta_dot_dpdn (8) — and pecnd (9): a steady call then touches no
-  // element array in memory at all
-  static constexpr int NCARRY = CARRY_LDS >= 2 ? 10 : (CARRY_LDS ? 5 : 1);
+  // element array in memory at all; 3: of those only vn0 and omega_p (where LDS has no room for all five: NLEV=128)
+  static constexpr int NCARRY = CARRY_LDS == 2 ? 10 : (CARRY_LDS == 3 ? 8 : (CARRY_LDS ? 5 : 1));
   double carry[NCARRY][CARRY_LDS ? NT_MAX * 64 : 1];
 };
 
@@ -149,7 +149,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   static_assert(!CARRY_LDS || STEPS, "CARRY_LDS: step loop only");
   static_assert(CARRY_IN == 0 || STEPS, "CARRY_IN: step loop only");
   static_assert(CARRY_LDS || (CARRY_IN & 6) == 0, "nm1 / tracer carry needs CARRY_LDS");
-  static_assert(CARRY_LDS >= 2 || (CARRY_IN & 8) == 0, "accumulator carry needs CARRY_LDS == 2");
+  static_assert(CARRY_LDS >= 2 || (CARRY_IN & 8) == 0, "accumulator carry needs CARRY_LDS >= 2");
   constexpr int carry_flags = CARRY_IN;
   constexpr bool carry_valid = STEPS && (CARRY_IN & 1);
   constexpr int PP = 16;               // GLL points per level
@@ -259,7 +259,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   }
   double geo_reg = 0.0;
   if (PERSIST && tid < G_SIZE) geo_reg = *geo_src((size_t)ie_s, tid);
-  if (tid < 16) s_dvv[tid] = k.Dvv[tid];
+  if (tid < 16 && !(carry_flags & 1)) s_dvv[tid] = k.Dvv[tid];
   if (VADV) {
     for (int idx = tid; idx < NT * 4 + 1; idx += THREADS) s_hybi[idx] = idx <= NLEV ? k.hybi[idx] : 0.0;
     if (tid < PP) {
@@ -314,14 +314,19 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         x.Tnm1 = stream_load<SNT>(T_nm1 + off);
         x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
       }
-      if (CARRY_LDS >= 2 && (carry_flags & 8)) {  // the previous call left the accumulators (and pecnd) in LDS
+      if (CARRY_LDS >= 2 && (carry_flags & 8)) {  // the previous call left the accumulators (2: and pecnd) in LDS
         const lds_cptr ca = lds_reread_ptr(&lds.carry[CARRY_LDS >= 2 ? 5 : 0][0] + (w * TPW + r) * 64 + lane);
         constexpr int Q = NT_MAX * 64;
         x.vn0.x = ca[0];
         x.vn0.y = ca[Q];
         x.om = ca[2 * Q];
-        x.eta = ca[3 * Q];
-        x.pec = ca[4 * Q];
+        if constexpr (CARRY_LDS == 2) {
+          x.eta = ca[3 * Q];
+          x.pec = ca[4 * Q];
+        } else {
+          x.pec = stream_load<SNT>(pecnd + off);
+          x.eta = stream_load<ANT>(eta + off);
+        }
       } else {
         x.vn0 = stream_load<ANT>(vn0 + off);
         x.om = stream_load<ANT>(omega_p + off);
@@ -342,10 +347,11 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     // previous element's last phase, ahead of its stores)
     if (PERSIST) {
       if (tid < G_SIZE) s_geo[tid] = geo_reg;
-    } else if (!(carry_flags & 8)) {  // (step loop, same element: the metric terms of the previous call are still there)
+    } else if (!(carry_flags & 1)) {  // (step loop, later call for the same element: the metric terms are still staged)
       for (int idx = tid; idx < G_SIZE; idx += THREADS) s_geo[idx] = stream_load<SNT>(geo_src(ie, idx));
     }
-    wg_barrier<PERSIST || STEPS>();  // also fences the previous element's last reads of the tile totals
+    // (a later call of the step loop staged nothing, and the loop's own barrier between the calls is the fence)
+    if (!(carry_flags & 1)) wg_barrier<PERSIST || STEPS>();  // also fences the previous element's last reads of the tile totals
 
     if (first) {
       make_np4_ctx(c, s_dvv, lane);
@@ -556,6 +562,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       const int st_mask = STORES >= 0 ? STORES : step_stores;
       const bool st_state = !STEPS || (st_mask & 1), st_phi = !STEPS || (st_mask & 2);
       const bool st_acc = CARRY_LDS < 2 || (st_mask & 4);  // accumulators carried in LDS: only the last call's reach memory
+      const bool st_eta = CARRY_LDS != 2 ? true : st_acc;    // (3: eta_dot_dpdn is not carried)
       if (st_state) stream_store<SNT>(v_np1 + off, vo);
       const double T_new = spheremp * (Tnm1 + k.dt2 * ttens);                         // P:253
       if (st_state) stream_store<SNT>(T_np1 + off, T_new);
@@ -575,15 +582,17 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         // ETA_COND: the update adds eta_ave_w * 0 (vertically Lagrangian), so the stored value
         // differs from the loaded one only for -0.0 or a non-finite eta_ave_w; storing only
         // then keeps the array bit-identical to the reference's and drops the write traffic.
-        if ((!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(cur.eta)) && st_acc)
+        if ((!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(cur.eta)) && st_eta)
           stream_store<ANT>(eta + off, e_new);
         if constexpr (CARRY_LDS >= 2) {
           constexpr int A = CARRY_LDS >= 2 ? 5 : 0;
           lds.carry[A][t * 64 + lane] = vn.x;
           lds.carry[A + 1][t * 64 + lane] = vn.y;
           lds.carry[A + 2][t * 64 + lane] = om_new;
-          lds.carry[A + 3][t * 64 + lane] = e_new;
-          if (!(carry_flags & 8)) lds.carry[A + 4][t * 64 + lane] = cur.pec;  // (first call; pecnd never changes)
+          if constexpr (CARRY_LDS == 2) {
+            lds.carry[A + 3][t * 64 + lane] = e_new;
+            if (!(carry_flags & 8)) lds.carry[A + 4][t * 64 + lane] = cur.pec;  // (first call; pecnd never changes)
+          }
         }
       }
       if constexpr (CARRY_LDS) {  // this call's n0 state is the next call's nm1

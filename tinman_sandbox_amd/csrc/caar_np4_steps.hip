@@ -134,13 +134,16 @@ hipError_t launch_np4_steps_72_onchip(const KernelArgs& k, int num_elems, int ns
   return launch_np4_steps<72, 3, 2, 0, 0, 0, 2>(k, num_elems, nsteps, rotate, s);
 }
 
-// NLEV=128: ONE workgroup per CU, 8 waves x 4 tiles, with the room that leaves in LDS (96 KB) used to carry the nm1 state
-// and the tracer block like NLEV=72 does: 0.356 ms per call at 12 500 elements against 0.515 for the two-workgroup 4 x 8
-// shape, whose LDS is full of parked scan results and which therefore reads nm1 from cache
-// (profiles/r03/steps_bench_128_8x4.log).  Default cache policy.
+// NLEV=128: ONE workgroup per CU, 8 waves x 4 tiles, with the room that leaves in LDS used to carry the nm1 state and the
+// tracer block like NLEV=72 does (96 KB: 0.356 ms per call at 12 500 elements against 0.515 for the two-workgroup 4 x 8
+// shape, whose LDS is full of parked scan results and which therefore reads nm1 from cache;
+// profiles/r03/steps_bench_128_8x4.log) and vn0 and omega_p as well (CARRY_LDS = 3, 145 KB: 0.342 against 0.348 with the
+// re-staging of the metric terms left out of the later calls).  Default cache policy.
 hipError_t launch_np4_steps_128_auto(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) {
-  return launch_np4_steps<128, 4, 2, 0, 0, 0, true>(k, num_elems, nsteps, rotate, s);
+  // CARRY_LDS = 3: vn0 and omega_p are carried in LDS too (145 KB; eta_dot_dpdn and pecnd still come from cache)
+  return launch_np4_steps<128, 4, 2, 0, 0, 0, 3>(k, num_elems, nsteps, rotate, s);
 }
+
 
 #ifdef CAAR_DEBUG
 long long debug_dp3d_count_np4_steps(int reset) { return debug_dp3d_count_of_this_tu(reset); }

@@ -134,9 +134,11 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
   double* const park_dp = s_park + lev0 * PP + lane;  // + r*PP; u, v follow at BLK strides
   // re-reads through a laundered LDS pointer: the compiler must not forward the parked values through registers
   const lds_cptr park_rd = lds_reread_ptr(park_dp);
-  if (tid < 64) s_dvvT[(tid & 7) * NP + (tid >> 3)] = k.Dvv[tid];  // Dvv[k][j] -> dvvT[j][k]
+  if (tid < 64 && !CARRY_IN) s_dvvT[(tid & 7) * NP + (tid >> 3)] = k.Dvv[tid];  // Dvv[k][j] -> dvvT[j][k]
   if (VADV && tid < PP) s_park[3 * BLK + tid] = 0.0;
-  for (int idx = tid; idx < G_SIZE; idx += THREADS) {
+  // (a later call of the step loop works on the same element: its metric terms are still staged, and the loop's barrier
+  // between the calls is the fence this barrier would be)
+  for (int idx = tid; idx < (CARRY_IN ? 0 : G_SIZE); idx += THREADS) {
     const double* src;
     if (idx < G_SPHEREMP) src = k.fcor + ie * PP + idx;
     else if (idx < G_METDET) src = k.spheremp + ie * PP + (idx - G_SPHEREMP);
@@ -147,7 +149,7 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
     else src = k.Dinv + ie * PP * 4 + (idx - G_DINV);
     s_geo[idx] = stream_load<SNT>(src);
   }
-  wg_sync();
+  if (!CARRY_IN) wg_sync();
 
   MfmaCtx mc;
   if (MFMA) mc = make_mfma_ctx(k.Dvv, lane);
