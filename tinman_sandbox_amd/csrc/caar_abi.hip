@@ -357,7 +357,10 @@ static int try_fused_steps(const CaarDims* dims, const CaarArrays* dev, const do
                            int nsteps, int rotate, void* stream, const caar::Config* cfg, const caar::LaunchChoice& ch,
                            int* rc_out) {
   *rc_out = CAAR_OK;
-  if (!g_fused_steps.load(std::memory_order_relaxed) || !cfg || !cfg->variants[ch.variant].launch_steps || p->rsplit == 0)
+  // (a non-finite eta_ave_w: the step loops leave out the later calls' `eta_dot_dpdn += eta_ave_w * 0`, which is the
+  // identity only where that product is a zero)
+  if (!g_fused_steps.load(std::memory_order_relaxed) || !cfg || !cfg->variants[ch.variant].launch_steps || p->rsplit == 0 ||
+      !(p->eta_ave_w * 0.0 == 0.0))
     return 0;
   int rc = check_common(dims, p);
   if (rc == CAAR_OK && (!dev || !dvv_dev)) rc = CAAR_EINVAL;

@@ -297,6 +297,12 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     double* __restrict__ eta = k.eta_dot_dpdn + ie * (BLK + PP) + wbase;
     double* __restrict__ eta_last = k.eta_dot_dpdn + ie * (BLK + PP) + BLK;
 
+    const double eta_zero = k.eta_ave_w * 0.0;  // eta_dot_dpdn_tmp == 0 (P:22,172): vertically Lagrangian
+    // A later call of a steady step loop: the previous call already added eta_ave_w * 0 to this element's eta_dot_dpdn, and
+    // x + 0 is a fixed point after one application (it only turns -0 into +0) — unless eta_ave_w * 0 is a NaN, and then
+    // the host does not take the step loop (caar_abi.hip try_fused_steps).  The read-modify-write that changes nothing is
+    // left out (CARRY_LDS == 2 carries the value in LDS instead).
+    constexpr bool eta_rmw = VADV || CARRY_LDS == 2 || !(carry_flags & 1);
     // Update-phase inputs of one tile (nm1 state, vn0, omega_p, pecnd, eta).
     struct TileIn {
       dbl2 vnm1, vn0;
@@ -325,13 +331,13 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
           x.pec = ca[4 * Q];
         } else {
           x.pec = stream_load<SNT>(pecnd + off);
-          x.eta = stream_load<ANT>(eta + off);
+          x.eta = eta_rmw ? stream_load<ANT>(eta + off) : 0.0;
         }
       } else {
         x.vn0 = stream_load<ANT>(vn0 + off);
         x.om = stream_load<ANT>(omega_p + off);
         x.pec = stream_load<SNT>(pecnd + off);
-        x.eta = stream_load<ANT>(eta + off);
+        x.eta = eta_rmw ? stream_load<ANT>(eta + off) : 0.0;
       }
       return x;
     };
@@ -432,7 +438,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     }
     TileIn cur = PF ? pre[TPW - 1] : load_tile(TPW - 1);  // in flight across the barrier
     double l_eta_last = 0.0;
-    if (tid < PP) l_eta_last = eta_last[kNp4Mfma ? (unsigned)tid : ulane];
+    if (tid < PP && eta_rmw) l_eta_last = eta_last[kNp4Mfma ? (unsigned)tid : ulane];
     wg_barrier<PERSIST || STEPS>();
 
     // PERSIST: request the next element's n0 inputs now; they land while phase 3 computes
@@ -457,7 +463,6 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     const double fcor = s_geo[G_FCOR + pt];
     const double spheremp = s_geo[G_SPHEREMP + pt];
     const double phis = s_geo[G_PHIS + pt];
-    const double eta_zero = k.eta_ave_w * 0.0;  // eta_dot_dpdn_tmp == 0 (P:22,172): vertically Lagrangian
 
     double below = 0.0;  // hydrostatic sum over the tiles below this wave's last tile
     for (int t2 = NT - 1; t2 > w * TPW + TPW - 1; --t2) below += s_tot_ht[t2 * PP + pt];
@@ -582,7 +587,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         // ETA_COND: the update adds eta_ave_w * 0 (vertically Lagrangian), so the stored value
         // differs from the loaded one only for -0.0 or a non-finite eta_ave_w; storing only
         // then keeps the array bit-identical to the reference's and drops the write traffic.
-        if ((!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(cur.eta)) && st_eta)
+        if ((!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(cur.eta)) && st_eta && eta_rmw)
           stream_store<ANT>(eta + off, e_new);
         if constexpr (CARRY_LDS >= 2) {
           constexpr int A = CARRY_LDS >= 2 ? 5 : 0;
@@ -614,7 +619,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       }
       cur = nxt;
     }
-    if (tid < PP) {
+    if (tid < PP && eta_rmw) {
       const double e_new = l_eta_last + eta_zero;                     // P:181
       if (!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(l_eta_last)) eta_last[kNp4Mfma ? (unsigned)tid : ulane] = e_new;
     }

@@ -56,15 +56,25 @@ struct Np8Lds {
 
 // STEPS: the body runs inside the step loop of caar_np8_steps_kernel (see caar_np4_steps.hip for the idea): barriers drain
 // the LDS counter only, and the call hands its np1 results to the next one — dp3d, u, v through the LDS park they already
-// live in, T through `Tc` (registers).  CARRY_IN (compile time): this call's n0 state arrives that way instead of being
-// loaded (every lane reads and writes only its own points, so what it stored is what it would load).
+// live in, T through `cy->T` (registers) — and keeps the n0 state it replaces there in `cy->m*` (registers): with rotating
+// time levels that is the next call's nm1 state.  CARRY_IN (compile time) 1: this call's n0 state arrives that way instead of
+// being loaded (every lane reads and writes only its own points, so what it stored is what it would load); 2: its nm1 state
+// too.  store_state = false: the np1 state is not written (a later call of the loop overwrites that time level and nothing
+// reads it from memory before).
+template <int TPW>
+struct Np8Carry {
+  double T[TPW];                               // T at n0 of this wave's levels
+  double mdp[TPW], mu[TPW], mv[TPW], mT[TPW];  // the state one call back (nm1 after the rotation)
+};
 template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T, bool BATCH, bool VADV = false, bool MFMA = false, int LA = 1,
-          bool STEPS = false, bool CARRY_IN = false>
-__device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLEV, TPW, BATCH, VADV, MFMA>& lds, double* Tc = nullptr,
-                                                 bool store_phi = true /* STEPS: false where a later call overwrites it */) {
+          bool STEPS = false, int CARRY_IN = 0>
+__device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLEV, TPW, BATCH, VADV, MFMA>& lds, Np8Carry<TPW>* cy = nullptr,
+                                                 bool store_phi = true /* STEPS: false where a later call overwrites it */,
+                                                 bool store_state = true) {
   using namespace np8;
   static_assert(!STEPS || (!VADV && !RELOAD_T && !BATCH), "step loop: plain Lagrangian form");
   static_assert(!CARRY_IN || STEPS, "CARRY_IN: step loop only");
+  constexpr bool CARRY_M = CARRY_IN == 2;
   auto wg_sync = [] {
     if constexpr (STEPS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // not the previous call's stores
     else __syncthreads();
@@ -130,7 +140,7 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
 #pragma unroll
   for (int r = 0; r < PD; ++r) ring[r] = load_n0(r);
   double T_local[RELOAD_T ? 1 : TPW], Tv[TPW];
-  double* const T = STEPS ? Tc : T_local;
+  double* const T = STEPS ? cy->T : T_local;
   double* const park_dp = s_park + lev0 * PP + lane;  // + r*PP; u, v follow at BLK strides
   // re-reads through a laundered LDS pointer: the compiler must not forward the parked values through registers
   const lds_cptr park_rd = lds_reread_ptr(park_dp);
@@ -229,6 +239,11 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
   double* __restrict__ eta = k.eta_dot_dpdn + ie * (BLK + PP) + wbase;
   double* __restrict__ eta_last = k.eta_dot_dpdn + ie * (BLK + PP) + BLK;
 
+  const double eta_zero = k.eta_ave_w * 0.0;  // eta_dot_dpdn_tmp == 0 (P:22,172)
+  // A later call of a steady step loop: the previous call already added eta_ave_w * 0 to this element's eta_dot_dpdn, and
+  // x + 0 is a fixed point after one application (it only turns -0 into +0) — unless eta_ave_w * 0 is a NaN, and then
+  // the host does not take the step loop (caar_abi.hip try_fused_steps).  The read-modify-write that changes nothing is left out.
+  constexpr bool eta_rmw = VADV || !CARRY_IN;
   struct LevelIn {
     dbl2 vnm1, vn0;
     double Tnm1, dpnm1, om, pec, eta, Tn0;
@@ -236,13 +251,18 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
   auto load_level = [&](int r) {
     const unsigned off = r * PP + ulane;
     LevelIn x;
-    x.vnm1 = stream_load<SNT>(v_nm1 + off);
-    x.Tnm1 = stream_load<SNT>(T_nm1 + off);
-    x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
+    if constexpr (CARRY_M) {  // in cy->m*
+      x.vnm1 = dbl2{0.0, 0.0};
+      x.Tnm1 = x.dpnm1 = 0.0;
+    } else {
+      x.vnm1 = stream_load<SNT>(v_nm1 + off);
+      x.Tnm1 = stream_load<SNT>(T_nm1 + off);
+      x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
+    }
     x.vn0 = stream_load<SNT>(vn0 + off);
     x.om = stream_load<SNT>(omega_p + off);
     x.pec = stream_load<SNT>(pecnd + off);
-    x.eta = stream_load<SNT>(eta + off);
+    x.eta = eta_rmw ? stream_load<SNT>(eta + off) : 0.0;
     x.Tn0 = RELOAD_T ? stream_load<SNT>(T_n0 + off) : 0.0;
     return x;
   };
@@ -276,20 +296,24 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
   }
 
   double l_eta_last = 0.0;
-  if (tid < PP) l_eta_last = eta_last[tid];
+  if (tid < PP && eta_rmw) l_eta_last = eta_last[tid];
   wg_sync();
 
   // ---- phase 3: level-local tendencies and update, top level of the wave first ----------
   double below = 0.0;  // hydrostatic sum over the waves below this one, bottom-up (P:293,302)
   for (int w2 = WAVES - 1; w2 > w; --w2) below += s_tot_ht[w2 * PP + pt];
-  const double eta_zero = k.eta_ave_w * 0.0;  // eta_dot_dpdn_tmp == 0 (P:22,172)
 
   double run_dp = base_dp, suml = base_div, run_ht = 0.0;
 #pragma unroll
   for (int r = 0; r < TPW; ++r) {
     const unsigned off = r * PP + ulane;
-    const LevelIn cur = ahead[r % LA];
+    LevelIn cur = ahead[r % LA];
     if (r + LA < TPW) ahead[r % LA] = load_level(r + LA);
+    if constexpr (CARRY_M) {
+      cur.vnm1 = dbl2{cy->mu[r], cy->mv[r]};
+      cur.Tnm1 = cy->mT[r];
+      cur.dpnm1 = cy->mdp[r];
+    }
 
     // The metric terms are re-read from LDS at every level instead of living in 26 registers
     // for the whole phase; the pointer is made opaque (but stays an LDS pointer: ds_read, not flat_load, which would
@@ -387,21 +411,25 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
     dbl2 vo;
     vo.x = spheremp * (cur.vnm1.x + k.dt2 * vtens1);                   // P:251
     vo.y = spheremp * (cur.vnm1.y + k.dt2 * vtens2);                   // P:252
-    stream_store<SNT>(v_np1 + off, vo);
+    if (!STEPS || store_state) stream_store<SNT>(v_np1 + off, vo);
     const double T_new = spheremp * (cur.Tnm1 + k.dt2 * ttens);       // P:253
-    stream_store<SNT>(T_np1 + off, T_new);
+    if (!STEPS || store_state) stream_store<SNT>(T_np1 + off, T_new);
     const double dp_new = VADV ? spheremp * (cur.dpnm1 - k.dt2 * (divdp[r] + eta_hi - eta_lo))  // X:515-517
                                : spheremp * (cur.dpnm1 - k.dt2 * divdp[r]);                     // P:254
     debug_check_dp3d(dp_new);  // CaarFunctor.hpp:82-97 check_dp3d (-DCAAR_DEBUG builds only)
-    stream_store<SNT>(dp_np1 + off, dp_new);
+    if (!STEPS || store_state) stream_store<SNT>(dp_np1 + off, dp_new);
     if (!STEPS || store_phi) stream_store<SNT>(phi_out + off, phi);
     stream_store<SNT>(omega_p + off, cur.om + k.eta_ave_w * om);                 // P:173
     dbl2 vn;
     vn.x = cur.vn0.x + k.eta_ave_w * (ur * dpr);                       // P:117
     vn.y = cur.vn0.y + k.eta_ave_w * (vr * dpr);                       // P:118
     stream_store<SNT>(vn0 + off, vn);
-    stream_store<SNT>(eta + off, cur.eta + (VADV ? k.eta_ave_w * eta_lo : eta_zero));  // P:172, X:271-272
-    if constexpr (STEPS) {  // the state just stored at np1 is the next call's n0: it replaces this level's n0 state
+    if (eta_rmw) stream_store<SNT>(eta + off, cur.eta + (VADV ? k.eta_ave_w * eta_lo : eta_zero));  // P:172, X:271-272
+    if constexpr (STEPS) {  // the state just stored at np1 is the next call's n0: it replaces this level's n0 state,
+      cy->mdp[r] = dpr;     // which is the next call's nm1
+      cy->mu[r] = ur;
+      cy->mv[r] = vr;
+      cy->mT[r] = Tr;
       park_dp[r * PP] = dp_new;
       park_dp[BLK + r * PP] = vo.x;
       park_dp[2 * BLK + r * PP] = vo.y;
@@ -409,7 +437,7 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (tid < PP) eta_last[tid] = l_eta_last + eta_zero;                 // P:181
+  if (tid < PP && eta_rmw) eta_last[tid] = l_eta_last + eta_zero;                 // P:181
 }
 
 template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T, bool BATCH, bool VADV = false, bool MFMA = false, int LA = 1>
@@ -421,14 +449,16 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
 // caar_run_steps / caar_launch_steps as ONE launch for NP=8 (the MFMA form; see caar_np4_steps.hip): every
 // workgroup makes all nsteps calls for its element.  With rotating, distinct time levels the first call loads everything
 // and every later call finds dp3d, u, v at n0 in the LDS park and T in registers, where the previous call left its np1
-// results; default cache policy, so that what is re-read (nm1 state, accumulators) is still on chip.  Bit-identical to
-// nsteps single launches.
+// results, and its nm1 state — the n0 state of the call before — in registers too (36 doubles per lane: a 512-thread
+// workgroup alone on its CU may use 256 VGPRs); the state is therefore stored by the last three calls only (the earlier
+// stores would be overwritten unread).  Default cache policy, so that the accumulators are re-read from the L2 that
+// holds them.  Bit-identical to nsteps single launches.
 template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, int LA>
 __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_steps_kernel(const KernelArgs k0, int nsteps, int rotate) {
   __shared__ Np8Lds<NLEV, TPW, false, false, true> lds;
   if (element_of_block(k0, blockIdx.x) < 0) return;
   int n0 = k0.n0, np1 = k0.np1, nm1 = k0.nm1;
-  double Tc[TPW];  // T at n0 of this wave's levels, handed from call to call
+  Np8Carry<TPW> cy;  // handed from call to call
   const bool steady = rotate && n0 != np1 && n0 != nm1 && np1 != nm1;  // uniform
   auto rotate_levels = [&] {  // TestData::update_time_levels
     const int t = np1;
@@ -445,15 +475,15 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_steps_kernel(c
   };
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   if (steady) {
-    caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, false>(args(), lds, Tc, nsteps == 1);
+    caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, 0>(args(), lds, &cy, nsteps == 1, nsteps <= 3);
     for (int s = 1; s < nsteps; ++s) {
       rotate_levels();
-      lds_barrier();  // the next call re-stages the metric terms and re-uses the tile totals: everybody is done with them
-      caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, true>(args(), lds, Tc, s == nsteps - 1);
+      lds_barrier();  // the next call re-uses the wave totals: everybody is done with them
+      caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, 2>(args(), lds, &cy, s == nsteps - 1, s >= nsteps - 3);
     }
   } else {
     for (int s = 0; s < nsteps; ++s) {
-      caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, false>(args(), lds, Tc, s == nsteps - 1);
+      caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, 0>(args(), lds, &cy, s == nsteps - 1);
       if (rotate) rotate_levels();
       lds_barrier();
     }
