@@ -142,7 +142,8 @@ int caar_launch(const CaarDims *dims, const CaarArrays *dev, const double *dvv_d
 /* `nsteps` consecutive calls (the driver loop main.cpp:113-121), with TestData::update_time_levels
  * (data_structures.cpp:174-180: np1, nm1, n0 <- nm1, n0, np1) between them if rotate != 0, on device-resident arrays:
  * one kernel launch where the selected variant has a step-loop kernel (see caar_set_fused_steps), else nsteps launches
- * of caar_launch.  Same arguments and rules as caar_launch; bit-identical to nsteps calls of it. */
+ * of caar_launch (also for rsplit == 0 and for a non-finite eta_ave_w).  Same arguments and rules as caar_launch;
+ * bit-identical to nsteps calls of it, in every array. */
 int caar_launch_steps(const CaarDims *dims, const CaarArrays *dev, const double *dvv_dev, const CaarParams *params,
                       int nsteps, int rotate, void *stream);
 

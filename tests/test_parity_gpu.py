@@ -552,7 +552,10 @@ def test_fused_steps_are_bit_identical_to_the_graph_of_single_launches(oracle, n
             for extra, nsteps, rotate in ((dict(), 5, 1), (dict(qn0=-1, nets=3, nete=30), 4, 1), (dict(dt2=0.125), 3, 0),
                                           (dict(n0=2, np1=0, nm1=1), 4, 1), (dict(n0=1, np1=1, nm1=0), 3, 1),
                                           (dict(n0=0, np1=1, nm1=0), 3, 1), (dict(n0=2, np1=2, nm1=1), 2, 0),
-                                          (dict(eta_ave_w=-0.5), 4, 1), (dict(eta_ave_w=float("inf")), 4, 1)):
+                                          (dict(eta_ave_w=-0.5), 4, 1), (dict(eta_ave_w=float("inf")), 4, 1),
+                                          # 1-3 and 6-7 calls: which calls store their state / phi depends on the count
+                                          (dict(), 1, 1), (dict(), 2, 1), (dict(n0=1, np1=2, nm1=0), 3, 1), (dict(), 6, 1),
+                                          (dict(qn0=-1), 7, 1)):
                 sc = po.default_scalars(nlev)
                 sc.update(dt2=0.25, qn0=1)
                 sc.update(extra)

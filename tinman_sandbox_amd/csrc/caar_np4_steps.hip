@@ -52,7 +52,7 @@ __device__ __forceinline__ void np4_step_loop(const KernelArgs& k0, int nsteps, 
     if constexpr (CARRY_LDS) {
       for (; s < nsteps - 3; ++s) {
         rotate_levels();
-        wg_barrier<true>();  // the next call re-stages Dvv and the metric terms in LDS: everybody is done reading them
+        wg_barrier<true>();  // the next call re-uses the tile totals: everybody is done reading them
         caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 0>(args(), lds, &carry);
       }
     }
@@ -116,14 +116,13 @@ CAAR_STEPS(128, 8, 2, 0, 0, 27)
 #undef CAAR_STEPS
 // What the default variants use.  From the second call on a call's inputs are the previous call's outputs: n0 state in
 // registers, (NLEV=72) nm1 state and tracer block in LDS, the rest still on chip if the accesses use the DEFAULT cache
-// policy — the opposite of what a single call wants.  NLEV=72: default policy at every size (0.221 ms per call at 10 000
-// elements against 0.244 all-streaming and 0.322 for single launches; 23 us against 30 hybrid at 1 024).  NLEV=128 (no LDS
-// carry): hybrid is 3 % ahead below ~3 700 elements, equal above.  profiles/r03/steps_bench_72_final.log, _128_final.log.
+// policy — the opposite of what a single call wants.  NLEV=72: default policy at every size (0.150 ms per call at 10 000
+// elements against 0.155 all-streaming and 0.322 for single launches).  profiles/r03/steps_bench_72_m2.log, _128_m2.log.
 hipError_t launch_np4_steps_72_onchip(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s);
 hipError_t launch_np4_steps_72_auto(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) {
   // Up to ~2 elements per CU a call is bound by the latency of ONE element's step: everything on chip (one 6 x 3 workgroup
   // per CU; 5.1 us per call at 64-256 elements against 7.3-7.7).  Beyond that two workgroups per CU, overlapping two
-  // elements, win (0.180 against 0.193 ms per call at 10 000 elements).  profiles/r03/steps_bench_72_onchip.log.
+  // elements, win (0.150 against 0.17-0.19 ms per call at 10 000 elements).  profiles/r03/steps_bench_72_onchip.log, _m2.log.
   return num_elems <= 640 ? launch_np4_steps_72_onchip(k, num_elems, nsteps, rotate, s)
                           : launch_np4_steps_72_0(k, num_elems, nsteps, rotate, s);
 }
@@ -137,8 +136,8 @@ hipError_t launch_np4_steps_72_onchip(const KernelArgs& k, int num_elems, int ns
 // NLEV=128: ONE workgroup per CU, 8 waves x 4 tiles, with the room that leaves in LDS used to carry the nm1 state and the
 // tracer block like NLEV=72 does (96 KB: 0.356 ms per call at 12 500 elements against 0.515 for the two-workgroup 4 x 8
 // shape, whose LDS is full of parked scan results and which therefore reads nm1 from cache;
-// profiles/r03/steps_bench_128_8x4.log) and vn0 and omega_p as well (CARRY_LDS = 3, 145 KB: 0.342 against 0.348 with the
-// re-staging of the metric terms left out of the later calls).  Default cache policy.
+// profiles/r03/steps_bench_128_8x4.log) and vn0 and omega_p as well (CARRY_LDS = 3, 145 KB: 0.339 ms per call,
+// profiles/r03/steps_bench_128_m2.log).  Default cache policy.
 hipError_t launch_np4_steps_128_auto(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) {
   // CARRY_LDS = 3: vn0 and omega_p are carried in LDS too (145 KB; eta_dot_dpdn and pecnd still come from cache)
   return launch_np4_steps<128, 4, 2, 0, 0, 0, 3>(k, num_elems, nsteps, rotate, s);
