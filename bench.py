@@ -471,7 +471,10 @@ def main():
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    # CAAR_BENCH_FORCE_DIST=1: a process group even for one rank (under torch.distributed.run --nproc-per-node 1), so that
+    # the RCCL path of the N>1 line — init with device_id, barriers, the MAX all-reduce and the gather on device tensors —
+    # can be exercised on a one-GPU box (tests/test_bench_gpu.py)
+    if world > 1 or os.environ.get("CAAR_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -598,7 +601,7 @@ def main():
             roof["frac_all_streaming"] = a0 / HBM_PEAK_GBS
             roof["kernel_ms_all_streaming"] = kernel_ms_streaming
             roof["kernel_all_streaming"] = streaming_kernel
-        if world > 1:
+        if dist is not None:
             roof["per_gpu"] = [{"rank": r, "elements": int(e), "kernel_ms": ms,
                                 "achieved": balg * e / (ms * 1e-3) / 1e9,
                                 "frac": balg * e / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}

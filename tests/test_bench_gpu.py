@@ -87,3 +87,28 @@ def test_two_rank_rehearsal_reports_backend_world_size_and_per_gpu_rates():
     assert [p["rank"] for p in per] == [0, 1] and all(p["elements"] == 1500 and p["kernel_ms"] > 0 for p in per)
     assert j["roofline"]["kernel_ms"] == max(p["kernel_ms"] for p in per)
     assert "cpu_baseline" not in j and "interleaved" not in j["roofline"]   # N=1 only
+
+
+def test_one_rank_under_rccl_takes_the_collective_path():
+    """The N>1 line's plumbing under the backend the driver uses (nccl = RCCL), on the one GPU a test box has: a process group of
+    one rank (CAAR_BENCH_FORCE_DIST=1) initialised with device_id, the barriers around the timed region, the MAX all-reduce and
+    the per-rank gather on device tensors all run through RCCL."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = _clean_env()
+    env["CAAR_BENCH_FORCE_DIST"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "1", "--steps", "4",
+                        "--warmup", "2", "--elems-per-gpu", "1500", "--no-spinup", "--no-other-configs", "--no-cpu-baseline",
+                        "--no-interleaved", "--no-live-traffic", "--no-steps-leg"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 1 and j["backend"] == "nccl" and j["dist_world_size"] == 1
+    assert abs(j["value"] - 1500 / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
+    assert j["ms_per_step"] <= j["ms_per_step_incl_closing_barrier"]
+    per = j["roofline"]["per_gpu"]
+    assert len(per) == 1 and per[0]["rank"] == 0 and per[0]["elements"] == 1500
+    assert j["roofline"]["kernel_ms"] == per[0]["kernel_ms"] > 0

@@ -16,7 +16,7 @@ from .caar import shard_range  # noqa: F401  (re-exported)
 def max_over_ranks(values, dist=None, device="cpu"):
     """Elementwise MAX of a list of floats over all ranks (identity without a group)."""
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():  # (also a group of one rank: the collective path, RCCL included, is what runs)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.tolist()
 
@@ -24,7 +24,7 @@ def max_over_ranks(values, dist=None, device="cpu"):
 def gather_over_ranks(values, dist=None, device="cpu"):
     """Every rank's list of floats, in rank order: [[rank 0's values], [rank 1's], ...]."""
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():
         parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
         dist.all_gather(parts, t)
         return [p.tolist() for p in parts]
