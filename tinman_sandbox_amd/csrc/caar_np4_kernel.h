@@ -159,9 +159,18 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   // tiles per element incl. dead ones (the last live one partly empty if NLEV % 4 != 0)
   const int NT = DYN ? (int)(blockDim.x >> 6) * TPW : NT_MAX;
   constexpr bool RAGGED = DYN || NLEV_T % 4 != 0;
-  const int THREADS = DYN ? (int)blockDim.x : NT_MAX / TPW * 64;
+  // Tiles per wave.  Where TPW does not divide the tile count (UNEVEN; NLEV=72 as 4 waves: 5, 5, 4, 4 of its 18 tiles) the
+  // first FULL waves own TPW consecutive tiles and the others TPW - 1: their last tile slot is dead, and everything that
+  // is per tile sits under a wave-uniform branch (tile_live).  Why: two 3-wave workgroups per CU put 2, 2, 1, 1 waves on the
+  // CU's four SIMDs and a kernel bound by instruction issue (the step loop) runs at the pace of the SIMD that holds two;
+  // 4-wave workgroups land one wave per SIMD each (tools/probes/simd_placement_probe.hip, profiles/r03/simd_placement_probe.log).
+  constexpr int WAVES_T = DYN ? DYNW : (NT_MAX + TPW - 1) / TPW;
+  constexpr int FULL = DYN ? DYNW : NT_MAX - WAVES_T * (TPW - 1);
+  constexpr bool UNEVEN = !DYN && FULL != WAVES_T;
+  const int THREADS = DYN ? (int)blockDim.x : WAVES_T * 64;
   const int BLK = NLEV * PP;           // doubles in one scalar field block
-  static_assert(DYN || NT_MAX % TPW == 0, "tile decomposition");
+  static_assert(DYN || (FULL >= 1 && FULL <= WAVES_T), "tile decomposition");
+  static_assert(!UNEVEN || (TPW >= 2 && !PERSIST && !VADV && NLEV_T % 4 == 0), "uneven tile counts: plain Lagrangian form");
   static_assert(!RAGGED || !PERSIST, "ragged level counts: non-persistent form only");
   static_assert(!VADV || (!PERSIST && !ETA_COND), "Eulerian branch: plain form only");
   static_assert(PARK == 0 || (!RAGGED && !PERSIST), "PARK: non-persistent form, level count a multiple of 4");
@@ -184,13 +193,17 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   // RAGGED (NLEV not a multiple of 4): the rows of the last tile beyond level NLEV-1 are dead:
   // their loads are masked and return 0, they contribute 0 to the three integrals, and they
   // store nothing.  DPP rows are one level each, so dead rows never feed live ones.
-  auto live_row = [&](int r) { return !RAGGED || ((w * TPW + r) * 4 + sub) < NLEV; };
+  const int tile0 = UNEVEN ? w * (TPW - 1) + (w < FULL ? w : FULL) : w * TPW;  // this wave's first tile (wave-uniform)
+  const bool last_live = !UNEVEN || w < FULL;                                    // ... and whether it owns TPW tiles
+  const int ntile = last_live ? TPW : TPW - 1;
+  auto tile_live = [&](int r) { return !UNEVEN || r < TPW - 1 || last_live; };
+  auto live_row = [&](int r) { return !RAGGED || ((tile0 + r) * 4 + sub) < NLEV; };
   // Addressing: every field pointer below is wave-uniform (element, time level and this
   // wave's first tile folded in: an SGPR pair) and is indexed by `r * 64 + ulane` with r
   // a compile-time tile number and ulane an UNSIGNED lane id, so each access is one
   // global_load/store with scalar base, one shared 32-bit lane offset and an immediate.
   const unsigned ulane = kNp4Mfma ? sub * 16 + pt : lane;  // this lane's offset inside a tile of the layout [lev][a][b]
-  const size_t wbase = (size_t)w * (TPW * 64);  // first point of this wave's tiles inside a field block
+  const size_t wbase = (size_t)tile0 * 64;  // first point of this wave's tiles inside a field block
 
   long long ie_s = PERSIST ? (blockIdx.x < (unsigned)k.nelem ? (long long)k.nets + blockIdx.x : -1)
                            : element_of_block(k, blockIdx.x);
@@ -209,7 +222,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
 #pragma unroll
     for (int r = 0; r < TPW; ++r) {
       x.dp[r] = x.u[r] = x.v[r] = x.T[r] = x.q[r] = 0.0;
-      if (live_row(r)) {
+      if (live_row(r) && tile_live(r)) {
         x.dp[r] = stream_load<SNT>(dp_n0 + r * 64 + ulane);
         const dbl2 uv = stream_load<SNT>(v_n0 + r * 64 + ulane);
         x.u[r] = uv.x;
@@ -231,7 +244,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     if (idx < G_DINV) return k.D + ie * PP * 4 + (idx - G_D);
     return k.Dinv + ie * PP * 4 + (idx - G_DINV);
   };
-  static_assert(!PERSIST || NT_MAX / TPW * 64 >= G_SIZE, "persistent form stages one metric value per thread");
+  static_assert(!PERSIST || WAVES_T * 64 >= G_SIZE, "persistent form stages one metric value per thread");
 
   // ---- phase 0: issue the n0 loads of the first element --------------------------------
   // STEPS: `in` is the caller's carry.  carry_valid (uniform): it already holds this call's n0 state — the previous call's
@@ -240,13 +253,19 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   N0In& in = STEPS ? *carry : in_local;
   if (STEPS && carry_valid) {
     if (CARRY_LDS && (carry_flags & 4)) {
-      const lds_cptr cq = lds_reread_ptr(&lds.carry[4][0] + (size_t)w * (TPW * 64) + lane);
+      const lds_cptr cq = lds_reread_ptr(&lds.carry[4][0] + (size_t)tile0 * 64 + lane);
 #pragma unroll
-      for (int r = 0; r < TPW; ++r) in.q[r] = MOIST ? cq[r * 64] : 0.0;
+      for (int r = 0; r < TPW; ++r) {
+        in.q[r] = 0.0;
+        if (MOIST && tile_live(r)) in.q[r] = cq[r * 64];
+      }
     } else {
       const double* __restrict__ Qdp = k.Qdp + (((size_t)ie_s * k.qsize_d + 0) * 2 + (MOIST ? k.qn0 : 0)) * BLK + wbase;
 #pragma unroll
-      for (int r = 0; r < TPW; ++r) in.q[r] = MOIST ? stream_load<SNT>(Qdp + r * 64 + ulane) : 0.0;
+      for (int r = 0; r < TPW; ++r) {
+        in.q[r] = 0.0;
+        if (MOIST && tile_live(r)) in.q[r] = stream_load<SNT>(Qdp + r * 64 + ulane);
+      }
     }
   } else {
     in = load_n0((size_t)ie_s);
@@ -254,7 +273,8 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   if constexpr (CARRY_LDS && MOIST) {
     if (!(carry_flags & 4)) {  // first call: the tracer block does not change from call to call (qn0 is fixed)
 #pragma unroll
-      for (int r = 0; r < TPW; ++r) lds.carry[4][(w * TPW + r) * 64 + lane] = in.q[r];
+      for (int r = 0; r < TPW; ++r)
+        if (tile_live(r)) lds.carry[4][(tile0 + r) * 64 + lane] = in.q[r];
     }
   }
   double geo_reg = 0.0;
@@ -311,7 +331,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     auto load_tile = [&](int r) {
       const unsigned off = r * 64 + ulane;
       TileIn x = {};
-      if (!live_row(r)) return x;
+      if (!live_row(r) || !tile_live(r)) return x;
       if (CARRY_LDS && (carry_flags & 2)) {
         // the previous call parked its n0 state (this call's nm1) in LDS: it is read where it is used, not a tile ahead
         // (LDS latency needs no prefetch, and four values fewer are live per tile in flight)
@@ -321,7 +341,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
       }
       if (CARRY_LDS >= 2 && (carry_flags & 8)) {  // the previous call left the accumulators (2: and pecnd) in LDS
-        const lds_cptr ca = lds_reread_ptr(&lds.carry[CARRY_LDS >= 2 ? 5 : 0][0] + (w * TPW + r) * 64 + lane);
+        const lds_cptr ca = lds_reread_ptr(&lds.carry[CARRY_LDS >= 2 ? 5 : 0][0] + (tile0 + r) * 64 + lane);
         constexpr int Q = NT_MAX * 64;
         x.vn0.x = ca[0];
         x.vn0.y = ca[Q];
@@ -376,7 +396,8 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     double divdp[TPW], Tv[TPW], ex_dp[TPW], ex_div[TPW];
 #pragma unroll
     for (int r = 0; r < TPW; ++r) {
-      const int t = w * TPW + r;
+      if (!tile_live(r)) continue;  // (wave-uniform)
+      const int t = tile0 + r;
       divdp[r] = divergence_sphere(c, Dinv, metdet, rmetdet, rrearth, u[r] * dp[r], v[r] * dp[r]);  // P:114-121
       Tv[r] = MOIST ? T[r] * (1.0 + k.rv_over_rd_m1 * (q[r] * recip(dp[r]))) : T[r];               // P:135,150-151
       if (RAGGED && !live_row(r)) Tv[r] = 0.0;  // dead row: dp == 0 made the line above NaN
@@ -400,13 +421,14 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     double sdot_sum = 0.0;  // VADV: column total of divdp (X:237)
     {
       double base_dp = 0.0, base_div = 0.0;
-      for (int t2 = 0; t2 < w * TPW; ++t2) {  // tiles above this wave's first tile (wave-uniform trip count)
+      for (int t2 = 0; t2 < tile0; ++t2) {  // tiles above this wave's first tile (wave-uniform trip count)
         base_dp += s_tot_dp[t2 * PP + pt];
         base_div += s_tot_div[t2 * PP + pt];
       }
 #pragma unroll
       for (int r = 0; r < TPW; ++r) {
-        const int t = w * TPW + r;
+        if (!tile_live(r)) continue;
+        const int t = tile0 + r;
         p[r] = (k.p_top + (base_dp + ex_dp[r])) + 0.5 * dp[r];  // P:84,94-96 in closed form
         suml[r] = base_div + ex_div[r];                          // P:327,339: sum of divdp above
         rp[r] = recip(p[r]);
@@ -427,7 +449,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         }
       }
       if (VADV) {
-        for (int t2 = w * TPW + TPW; t2 < NT; ++t2) base_div += s_tot_div[t2 * PP + pt];
+        for (int t2 = tile0 + ntile; t2 < NT; ++t2) base_div += s_tot_div[t2 * PP + pt];
         sdot_sum = base_div;
       }
     }
@@ -465,15 +487,19 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     const double phis = s_geo[G_PHIS + pt];
 
     double below = 0.0;  // hydrostatic sum over the tiles below this wave's last tile
-    for (int t2 = NT - 1; t2 > w * TPW + TPW - 1; --t2) below += s_tot_ht[t2 * PP + pt];
+    for (int t2 = NT - 1; t2 > tile0 + ntile - 1; --t2) below += s_tot_ht[t2 * PP + pt];
 
 #pragma unroll
     for (int rr = 0; rr < TPW; ++rr) {
       const int r = TPW - 1 - rr;  // bottom tile of the wave first: `below` accumulates upwards
-      const int t = w * TPW + r;
+      const int t = tile0 + r;
       const unsigned off = r * 64 + ulane;
       TileIn nxt = cur;
       if (r > 0) nxt = PF ? pre[r - 1] : load_tile(r - 1);
+      if (!tile_live(r)) {  // (wave-uniform; only r == TPW - 1 of an UNEVEN shape)
+        cur = nxt;
+        continue;
+      }
       double p_r, suml_r, exht_r, divdp_r, Tv_r;  // this tile's scan results (registers, or parked in LDS)
       if constexpr (PARK == 0) {
         p_r = p[r];
@@ -642,7 +668,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
 //      reference's driver loop) finds them there instead of in HBM.  Both code paths live in the
 //      kernel; the choice is uniform per workgroup.
 template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, bool PERSIST, bool ETA_COND, bool VADV = false, int DYNW = 8, int PARK = 0>
-__global__ __launch_bounds__(NLEV_T ? (NLEV_T + 3) / 4 / TPW * 64 : DYNW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
+__global__ __launch_bounds__(NLEV_T ? ((NLEV_T + 3) / 4 + TPW - 1) / TPW * 64 : DYNW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
   __shared__ Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW, PARK> lds;
   if constexpr (POL == 2) {
     static_assert(!PERSIST, "hybrid cache policy: non-persistent form only");

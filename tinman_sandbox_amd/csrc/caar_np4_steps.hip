@@ -78,7 +78,7 @@ __device__ __forceinline__ void np4_step_loop(const KernelArgs& k0, int nsteps, 
 // CARRY_LDS: the nm1 state and the tracer block travel from call to call in LDS (NLEV=72: 46 KB more, two workgroups per CU
 // still fit; NLEV=128 has no room next to its parked scan results).
 template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, int PARK, int CARRY_LDS>
-__global__ __launch_bounds__((NLEV_T + 3) / 4 / TPW * 64, MINW) void caar_np4_steps_kernel(const KernelArgs k0, int nsteps, int rotate) {
+__global__ __launch_bounds__(((NLEV_T + 3) / 4 + TPW - 1) / TPW * 64, MINW) void caar_np4_steps_kernel(const KernelArgs k0, int nsteps, int rotate) {
   __shared__ Np4Lds<NLEV_T, TPW, false, false, 8, PARK, CARRY_LDS> lds;
   const long long ie_s = element_of_block(k0, blockIdx.x);
   if (ie_s < 0) return;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__((NLEV_T + 3) / 4 / TPW * 64, MINW) void caar_np4_st
 
 template <int NLEV, int TPW, int MINW, int POL, int PF, int PARK, int CARRY_LDS = (NLEV <= 72 ? 1 : 0)>
 static hipError_t launch_np4_steps(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t stream) {
-  constexpr int THREADS = (NLEV + 3) / 4 / TPW * 64;
+  constexpr int THREADS = ((NLEV + 3) / 4 + TPW - 1) / TPW * 64;
   if (k.vadv) return hipErrorNotSupported;  // the Eulerian form steps through the graph of single launches
   const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
   if (k.qn0 >= 0)
@@ -107,23 +107,33 @@ static hipError_t launch_np4_steps(const KernelArgs& k, int num_elems, int nstep
   hipError_t launch_np4_steps_##NLEV##_##POL(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) { \
     return launch_np4_steps<NLEV, TPW, MINW, POL, PF, PARK>(k, num_elems, nsteps, rotate, s);                        \
   }
-CAAR_STEPS(72, 6, 2, 2, 0, 24)
-CAAR_STEPS(72, 6, 2, 1, 0, 24)
-CAAR_STEPS(72, 6, 2, 0, 0, 24)
+// NLEV=72: FOUR waves with 5, 5, 4, 4 of the 18 tiles (caar_np4_kernel.h UNEVEN), two workgroups per CU: the loop is bound by
+// instruction issue, and two 3 x 6 workgroups put 2, 2, 1, 1 waves on a CU's four SIMDs (12 tiles per pair of elements on
+// the busiest) where two 4-wave ones put one wave each on every SIMD (9-10): 0.134 against 0.151 ms per call at 10 000
+// elements (profiles/r03/steps_bench_72_4w.log, simd_placement_probe.log).  Nothing parked: five tiles fit the registers.
+CAAR_STEPS(72, 5, 2, 2, 0, 0)
+CAAR_STEPS(72, 5, 2, 1, 0, 0)
+CAAR_STEPS(72, 5, 2, 0, 0, 0)
 CAAR_STEPS(128, 8, 2, 2, 0, 27)
 CAAR_STEPS(128, 8, 2, 1, 0, 27)
 CAAR_STEPS(128, 8, 2, 0, 0, 27)
 #undef CAAR_STEPS
 // What the default variants use.  From the second call on a call's inputs are the previous call's outputs: n0 state in
 // registers, (NLEV=72) nm1 state and tracer block in LDS, the rest still on chip if the accesses use the DEFAULT cache
-// policy — the opposite of what a single call wants.  NLEV=72: default policy at every size (0.150 ms per call at 10 000
-// elements against 0.155 all-streaming and 0.322 for single launches).  profiles/r03/steps_bench_72_m2.log, _128_m2.log.
+// policy — the opposite of what a single call wants.  NLEV=72: default policy at every size (0.134 ms per call at 10 000
+// elements against 0.322 for single launches).  profiles/r03/steps_bench_72_4w_thresh.log, steps_bench_128_m2.log.
 hipError_t launch_np4_steps_72_onchip(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s);
 hipError_t launch_np4_steps_72_auto(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) {
-  // Up to ~2 elements per CU a call is bound by the latency of ONE element's step: everything on chip (one 6 x 3 workgroup
-  // per CU; 5.1 us per call at 64-256 elements against 7.3-7.7).  Beyond that two workgroups per CU, overlapping two
-  // elements, win (0.150 against 0.17-0.19 ms per call at 10 000 elements).  profiles/r03/steps_bench_72_onchip.log, _m2.log.
-  return num_elems <= 640 ? launch_np4_steps_72_onchip(k, num_elems, nsteps, rotate, s)
+  // Up to one element per CU a call is bound by the latency of ONE element's step: everything on chip (one 6 x 3 workgroup
+  // per CU; 5.1 us per call at 64-256 elements against 5.5-5.7).  Beyond that two 4-wave workgroups per CU, overlapping two
+  // elements, win (7.6 against 9.9 us at 384 elements, 0.134 against 0.17-0.19 ms at 10 000).
+  // profiles/r03/steps_bench_72_4w_thresh.log.
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  return num_elems <= cus ? launch_np4_steps_72_onchip(k, num_elems, nsteps, rotate, s)
                           : launch_np4_steps_72_0(k, num_elems, nsteps, rotate, s);
 }
 // NLEV=72 with EVERYTHING a call needs from its predecessor on chip (CARRY_LDS = 2: the accumulators and pecnd in LDS as
