@@ -138,7 +138,7 @@ struct Np4N0In {
 // call's n0 state (dp3d, u, v, T), 2 = lds.carry holds its nm1 state, 4 = lds.carry holds its tracer block (2 and 4 only
 // with CARRY_LDS), 8 = lds.carry holds the accumulators and pecnd, and the metric terms are still staged (CARRY_LDS == 2).
 // Every STEPS call hands the same things on to the next one.
-template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW, int PARK = 0, bool STEPS = false, int CARRY_LDS = 0, int CARRY_IN = 0, int STORES = -1>
+template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW, int PARK = 0, bool STEPS = false, int CARRY_LDS = 0, int CARRY_IN = 0, int STORES = -1, int WAVES = 0>
 __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW, PARK, CARRY_LDS>& lds,
                                                  Np4N0In<TPW>* carry = nullptr, int step_stores = 3) {
   // step_stores (uniform; STEPS only; else all; STORES >= 0: the same as a compile-time constant, for the hot loop):
@@ -164,11 +164,12 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   // is per tile sits under a wave-uniform branch (tile_live).  Why: two 3-wave workgroups per CU put 2, 2, 1, 1 waves on the
   // CU's four SIMDs and a kernel bound by instruction issue (the step loop) runs at the pace of the SIMD that holds two;
   // 4-wave workgroups land one wave per SIMD each (tools/probes/simd_placement_probe.hip, profiles/r03/simd_placement_probe.log).
-  constexpr int WAVES_T = DYN ? DYNW : (NT_MAX + TPW - 1) / TPW;
+  constexpr int WAVES_T = DYN ? DYNW : (WAVES ? WAVES : (NT_MAX + TPW - 1) / TPW);  // WAVES: more waves than ceil(tiles / TPW), e.g. 18 tiles as 3, 3, 2, 2, 2, 2, 2, 2
   constexpr int FULL = DYN ? DYNW : NT_MAX - WAVES_T * (TPW - 1);
   constexpr bool UNEVEN = !DYN && FULL != WAVES_T;
   const int THREADS = DYN ? (int)blockDim.x : WAVES_T * 64;
   const int BLK = NLEV * PP;           // doubles in one scalar field block
+  static_assert(!WAVES || !DYN, "WAVES: compile-time level counts only");
   static_assert(DYN || (FULL >= 1 && FULL <= WAVES_T), "tile decomposition");
   static_assert(!UNEVEN || (TPW >= 2 && !PERSIST && !VADV && NLEV_T % 4 == 0), "uneven tile counts: plain Lagrangian form");
   static_assert(!RAGGED || !PERSIST, "ragged level counts: non-persistent form only");

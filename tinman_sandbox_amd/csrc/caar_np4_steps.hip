@@ -20,7 +20,7 @@ namespace caar {
 // state from registers and (CARRY_LDS) its nm1 state and tracer block from LDS — two instantiations of the body, the
 // steady one with no n0 / nm1 / Qdp loads at all.  Without rotation, or with aliased time levels, every call loads
 // what it reads (what a lane stored is what it loads: same results, no carry).
-template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, int PARK, int CARRY_LDS>
+template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, int PARK, int CARRY_LDS, int WAVES>
 __device__ __forceinline__ void np4_step_loop(const KernelArgs& k0, int nsteps, int rotate,
                                               Np4Lds<NLEV_T, TPW, false, false, 8, PARK, CARRY_LDS>& lds) {
   int n0 = k0.n0, np1 = k0.np1, nm1 = k0.nm1;
@@ -46,29 +46,29 @@ __device__ __forceinline__ void np4_step_loop(const KernelArgs& k0, int nsteps, 
   // 1 .. nsteps-4 store neither, calls nsteps-3 .. nsteps-2 the state, the last call both.
   if (steady) {
     const int first_mask = ((!CARRY_LDS || nsteps <= 3) ? 1 : 0) | (nsteps == 1 ? 6 : 0);
-    caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0>(args(), lds, &carry, first_mask);
+    caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0, -1, WAVES>(args(), lds, &carry, first_mask);
     constexpr int CIN = CARRY_LDS >= 2 ? 15 : (CARRY_LDS ? 7 : 1);
     int s = 1;
     if constexpr (CARRY_LDS) {
       for (; s < nsteps - 3; ++s) {
         rotate_levels();
         wg_barrier<true>();  // the next call re-uses the tile totals: everybody is done reading them
-        caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 0>(args(), lds, &carry);
+        caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 0, WAVES>(args(), lds, &carry);
       }
     }
     for (; s < nsteps - 1; ++s) {
       rotate_levels();
       wg_barrier<true>();
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 1>(args(), lds, &carry);
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 1, WAVES>(args(), lds, &carry);
     }
     if (s < nsteps) {
       rotate_levels();
       wg_barrier<true>();
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 7>(args(), lds, &carry);
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 7, WAVES>(args(), lds, &carry);
     }
   } else {
     for (int s = 0; s < nsteps; ++s) {  // (no carry: every call stores everything except a phi that will be overwritten)
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0>(args(), lds, &carry, 1 | 4 | (s == nsteps - 1 ? 2 : 0));
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0, -1, WAVES>(args(), lds, &carry, 1 | 4 | (s == nsteps - 1 ? 2 : 0));
       if (rotate) rotate_levels();
       wg_barrier<true>();
     }
@@ -77,28 +77,28 @@ __device__ __forceinline__ void np4_step_loop(const KernelArgs& k0, int nsteps, 
 
 // CARRY_LDS: the nm1 state and the tracer block travel from call to call in LDS (NLEV=72: 46 KB more, two workgroups per CU
 // still fit; NLEV=128 has no room next to its parked scan results).
-template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, int PARK, int CARRY_LDS>
-__global__ __launch_bounds__(((NLEV_T + 3) / 4 + TPW - 1) / TPW * 64, MINW) void caar_np4_steps_kernel(const KernelArgs k0, int nsteps, int rotate) {
+template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, int PARK, int CARRY_LDS, int WAVES>
+__global__ __launch_bounds__((WAVES ? WAVES : ((NLEV_T + 3) / 4 + TPW - 1) / TPW) * 64, MINW) void caar_np4_steps_kernel(const KernelArgs k0, int nsteps, int rotate) {
   __shared__ Np4Lds<NLEV_T, TPW, false, false, 8, PARK, CARRY_LDS> lds;
   const long long ie_s = element_of_block(k0, blockIdx.x);
   if (ie_s < 0) return;
   if constexpr (POL == 2) {
-    if (element_is_cached(k0, ie_s - k0.nets)) np4_step_loop<NLEV_T, TPW, MINW, MOIST, true, false, PF, PARK, CARRY_LDS>(k0, nsteps, rotate, lds);
-    else np4_step_loop<NLEV_T, TPW, MINW, MOIST, true, true, PF, PARK, CARRY_LDS>(k0, nsteps, rotate, lds);
+    if (element_is_cached(k0, ie_s - k0.nets)) np4_step_loop<NLEV_T, TPW, MINW, MOIST, true, false, PF, PARK, CARRY_LDS, WAVES>(k0, nsteps, rotate, lds);
+    else np4_step_loop<NLEV_T, TPW, MINW, MOIST, true, true, PF, PARK, CARRY_LDS, WAVES>(k0, nsteps, rotate, lds);
   } else {
-    np4_step_loop<NLEV_T, TPW, MINW, MOIST, POL == 1, POL == 1, PF, PARK, CARRY_LDS>(k0, nsteps, rotate, lds);
+    np4_step_loop<NLEV_T, TPW, MINW, MOIST, POL == 1, POL == 1, PF, PARK, CARRY_LDS, WAVES>(k0, nsteps, rotate, lds);
   }
 }
 
-template <int NLEV, int TPW, int MINW, int POL, int PF, int PARK, int CARRY_LDS = (NLEV <= 72 ? 1 : 0)>
+template <int NLEV, int TPW, int MINW, int POL, int PF, int PARK, int CARRY_LDS = (NLEV <= 72 ? 1 : 0), int WAVES = 0>
 static hipError_t launch_np4_steps(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t stream) {
-  constexpr int THREADS = ((NLEV + 3) / 4 + TPW - 1) / TPW * 64;
+  constexpr int THREADS = (WAVES ? WAVES : ((NLEV + 3) / 4 + TPW - 1) / TPW) * 64;
   if (k.vadv) return hipErrorNotSupported;  // the Eulerian form steps through the graph of single launches
   const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
   if (k.qn0 >= 0)
-    hipLaunchKernelGGL((caar_np4_steps_kernel<NLEV, TPW, MINW, true, POL, PF, PARK, CARRY_LDS>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
+    hipLaunchKernelGGL((caar_np4_steps_kernel<NLEV, TPW, MINW, true, POL, PF, PARK, CARRY_LDS, WAVES>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
   else
-    hipLaunchKernelGGL((caar_np4_steps_kernel<NLEV, TPW, MINW, false, POL, PF, PARK, CARRY_LDS>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
+    hipLaunchKernelGGL((caar_np4_steps_kernel<NLEV, TPW, MINW, false, POL, PF, PARK, CARRY_LDS, WAVES>), dim3(grid), dim3(THREADS), 0, stream, k, nsteps, rotate);
   return hipGetLastError();
 }
 
@@ -124,8 +124,8 @@ CAAR_STEPS(128, 8, 2, 0, 0, 27)
 // elements against 0.322 for single launches).  profiles/r03/steps_bench_72_4w_thresh.log, steps_bench_128_m2.log.
 hipError_t launch_np4_steps_72_onchip(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s);
 hipError_t launch_np4_steps_72_auto(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) {
-  // Up to one element per CU a call is bound by the latency of ONE element's step: everything on chip (one 6 x 3 workgroup
-  // per CU; 5.1 us per call at 64-256 elements against 5.5-5.7).  Beyond that two 4-wave workgroups per CU, overlapping two
+  // Up to one element per CU a call is bound by the latency of ONE element's step: everything on chip (one 8-wave workgroup
+  // per CU; 4.7-4.9 us per call at 64-256 elements against 5.5-5.7).  Beyond that two 4-wave workgroups per CU, overlapping two
   // elements, win (7.6 against 9.9 us at 384 elements, 0.134 against 0.17-0.19 ms at 10 000).
   // profiles/r03/steps_bench_72_4w_thresh.log.
   static const int cus = [] {
@@ -137,10 +137,12 @@ hipError_t launch_np4_steps_72_auto(const KernelArgs& k, int num_elems, int nste
                           : launch_np4_steps_72_0(k, num_elems, nsteps, rotate, s);
 }
 // NLEV=72 with EVERYTHING a call needs from its predecessor on chip (CARRY_LDS = 2: the accumulators and pecnd in LDS as
-// well, the metric terms left staged): one workgroup per CU, 6 waves x 3 tiles, 101 KB of LDS.  A steady call then touches
-// no element array in memory.
+// well, the metric terms left staged): one workgroup per CU, 101 KB of LDS.  A steady call then touches no element array
+// in memory.  EIGHT waves with 3, 3, 2, 2, 2, 2, 2, 2 of the 18 tiles: two waves on every SIMD with 5, 5, 4, 4 tiles between
+// them, where 6 waves x 3 tiles put 6, 3, 3, 6 (4.7-4.9 against 5.1-5.2 us per call at 64-256 elements,
+// profiles/r03/steps_bench_72_onchip8.log).
 hipError_t launch_np4_steps_72_onchip(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) {
-  return launch_np4_steps<72, 3, 2, 0, 0, 0, 2>(k, num_elems, nsteps, rotate, s);
+  return launch_np4_steps<72, 3, 2, 0, 0, 0, 2, 8>(k, num_elems, nsteps, rotate, s);
 }
 
 // NLEV=128: ONE workgroup per CU, 8 waves x 4 tiles, with the room that leaves in LDS used to carry the nm1 state and the
