@@ -96,9 +96,12 @@ struct Np4Lds {
   static constexpr int COL = VADV ? (NT_MAX * 4 + 2) * PP : 1;
   double dvv[16];
   double geo_buf[PERSIST ? 2 : 1][208];  // G_SIZE; double-buffered across elements
-  double tot_dp[NT_MAX * PP];            // sum of dp over each tile
-  double tot_div[NT_MAX * PP];           // sum of divdp over each tile
-  double tot_ht[NT_MAX * PP];            // sum of Rgas*T_v*dp/p over each tile
+  // (CARRY_LDS, the step loops that carry state: two sets, used by alternate calls, so that a call's first phase may
+  // overwrite tile totals while slower waves still read the previous call's in its last phase — no barrier between calls)
+  static constexpr int TOTB = CARRY_LDS ? 2 : 1;
+  double tot_dp[TOTB * NT_MAX * PP];     // sum of dp over each tile
+  double tot_div[TOTB * NT_MAX * PP];    // sum of divdp over each tile
+  double tot_ht[TOTB * NT_MAX * PP];     // sum of Rgas*T_v*dp/p over each tile
   // VADV: T, u, v at n0 of the whole column, [field][1 + level][pt] with a zero row above the top level and
   // below the bottom one (and room for the dead rows of a ragged last tile)
   double col[3][COL];
@@ -140,7 +143,7 @@ struct Np4N0In {
 // Every STEPS call hands the same things on to the next one.
 template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW, int PARK = 0, bool STEPS = false, int CARRY_LDS = 0, int CARRY_IN = 0, int STORES = -1, int WAVES = 0>
 __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW, PARK, CARRY_LDS>& lds,
-                                                 Np4N0In<TPW>* carry = nullptr, int step_stores = 3) {
+                                                 Np4N0In<TPW>* carry = nullptr, int step_stores = 3, int tot_par = 0) {
   // step_stores (uniform; STEPS only; else all; STORES >= 0: the same as a compile-time constant, for the hot loop):
   // bit 1 = store the np1 state (v, T, dp3d), bit 2 = store derived_phi.  The
   // step loop leaves them out where a later call of the same launch overwrites them and nothing reads them in between:
@@ -179,9 +182,10 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   static_assert(G_SIZE == 208, "Np4Lds::geo_buf");
   double* const s_dvv = lds.dvv;
   auto& s_geo_buf = lds.geo_buf;
-  double* const s_tot_dp = lds.tot_dp;
-  double* const s_tot_div = lds.tot_div;
-  double* const s_tot_ht = lds.tot_ht;
+  // tot_par (uniform; CARRY_LDS step loops): which of the two sets of tile totals this call uses
+  double* const s_tot_dp = lds.tot_dp + (CARRY_LDS ? tot_par * (NT_MAX * PP) : 0);
+  double* const s_tot_div = lds.tot_div + (CARRY_LDS ? tot_par * (NT_MAX * PP) : 0);
+  double* const s_tot_ht = lds.tot_ht + (CARRY_LDS ? tot_par * (NT_MAX * PP) : 0);
   auto& s_col = lds.col;
   double* const s_hybi = lds.hybi;
 

@@ -48,23 +48,29 @@ __device__ __forceinline__ void np4_step_loop(const KernelArgs& k0, int nsteps, 
     const int first_mask = ((!CARRY_LDS || nsteps <= 3) ? 1 : 0) | (nsteps == 1 ? 6 : 0);
     caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0, -1, WAVES>(args(), lds, &carry, first_mask);
     constexpr int CIN = CARRY_LDS >= 2 ? 15 : (CARRY_LDS ? 7 : 1);
+    // Between two calls: nothing a wave reads in LDS was written by another wave except the tile totals, and with state
+    // carried in LDS (CARRY_LDS) those exist twice and alternate calls use alternate sets — a wave that is done with call s
+    // starts call s+1 without waiting for the others (they meet at the barrier behind its first phase; by the time anyone
+    // writes a set again, two barriers later, everybody has left the phase that read it).  Without the LDS carry the sets
+    // do not fit next to the parked scan results: one barrier.
+    auto between = [&] {
+      rotate_levels();
+      if constexpr (!CARRY_LDS) wg_barrier<true>();
+    };
     int s = 1;
     if constexpr (CARRY_LDS) {
       for (; s < nsteps - 3; ++s) {
-        rotate_levels();
-        wg_barrier<true>();  // the next call re-uses the tile totals: everybody is done reading them
-        caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 0, WAVES>(args(), lds, &carry);
+        between();
+        caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 0, WAVES>(args(), lds, &carry, 3, s & 1);
       }
     }
     for (; s < nsteps - 1; ++s) {
-      rotate_levels();
-      wg_barrier<true>();
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 1, WAVES>(args(), lds, &carry);
+      between();
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 1, WAVES>(args(), lds, &carry, 3, s & 1);
     }
     if (s < nsteps) {
-      rotate_levels();
-      wg_barrier<true>();
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 7, WAVES>(args(), lds, &carry);
+      between();
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, CIN, 7, WAVES>(args(), lds, &carry, 3, s & 1);
     }
   } else {
     for (int s = 0; s < nsteps; ++s) {  // (no carry: every call stores everything except a phi that will be overwritten)

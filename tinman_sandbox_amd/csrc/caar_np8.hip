@@ -41,16 +41,18 @@ namespace caar {
 // LA: how many levels ahead the update-phase inputs (nm1 state, vn0, omega_p, pecnd, eta) are requested.
 // The workgroup's LDS, declared ONCE in each kernel and shared by the instantiations of the body inside it (the step loop has
 // two: as function-local __shared__ arrays every buffer would exist twice, 260 KB).
-template <int NLEV, int TPW, bool BATCH, bool VADV, bool MFMA>
+// DB (the step loop): two sets of wave totals, used by alternate calls — a call's first phase may then overwrite totals
+// while slower waves still read the previous call's in its last phase, and the calls need no barrier between them.
+template <int NLEV, int TPW, bool BATCH, bool VADV, bool MFMA, bool DB = false>
 struct Np8Lds {
   static constexpr int WAVES = NLEV / TPW, BLK = NLEV * np8::PP, SLOTS = BATCH ? 5 : 1;
   __attribute__((aligned(16))) double dvvT[64];
   __attribute__((aligned(16))) double geo[np8::G_SIZE];
   __attribute__((aligned(16))) double tile[MFMA ? 1 : WAVES * 64 * SLOTS];  // LDS tile slots per wave (BATCH: p, T, Ephi, vcov1, vcov0)
   double park[3 * BLK + (VADV ? np8::PP : 0)];  // dp, u, v of every level, [field][lev][pt] (+ a zero row for VADV)
-  double tot_dp[WAVES * np8::PP];               // per wave: sum of dp over its levels
-  double tot_div[WAVES * np8::PP];              // ... of divdp
-  double tot_ht[WAVES * np8::PP];               // ... of Rgas*T_v*dp/p
+  double tot_dp[(DB ? 2 : 1) * WAVES * np8::PP];   // per wave: sum of dp over its levels
+  double tot_div[(DB ? 2 : 1) * WAVES * np8::PP];  // ... of divdp
+  double tot_ht[(DB ? 2 : 1) * WAVES * np8::PP];   // ... of Rgas*T_v*dp/p
   double Thalo[VADV ? WAVES * 2 * np8::PP : 1]; // VADV: T of each wave's first / last level
 };
 
@@ -68,9 +70,9 @@ struct Np8Carry {
 };
 template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T, bool BATCH, bool VADV = false, bool MFMA = false, int LA = 1,
           bool STEPS = false, int CARRY_IN = 0>
-__device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLEV, TPW, BATCH, VADV, MFMA>& lds, Np8Carry<TPW>* cy = nullptr,
+__device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLEV, TPW, BATCH, VADV, MFMA, STEPS>& lds, Np8Carry<TPW>* cy = nullptr,
                                                  bool store_phi = true /* STEPS: false where a later call overwrites it */,
-                                                 bool store_state = true) {
+                                                 bool store_state = true, int tot_par = 0 /* STEPS: which set of wave totals */) {
   using namespace np8;
   static_assert(!STEPS || (!VADV && !RELOAD_T && !BATCH), "step loop: plain Lagrangian form");
   static_assert(!CARRY_IN || STEPS, "CARRY_IN: step loop only");
@@ -91,9 +93,9 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
   double* const s_geo = lds.geo;
   double* const s_tile = lds.tile;
   double* const s_park = lds.park;
-  double* const s_tot_dp = lds.tot_dp;
-  double* const s_tot_div = lds.tot_div;
-  double* const s_tot_ht = lds.tot_ht;
+  double* const s_tot_dp = lds.tot_dp + (STEPS ? tot_par * (NLEV / TPW * np8::PP) : 0);
+  double* const s_tot_div = lds.tot_div + (STEPS ? tot_par * (NLEV / TPW * np8::PP) : 0);
+  double* const s_tot_ht = lds.tot_ht + (STEPS ? tot_par * (NLEV / TPW * np8::PP) : 0);
   double* const s_Thalo = lds.Thalo;
 
   const int tid = threadIdx.x;
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const K
 // holds them.  Bit-identical to nsteps single launches.
 template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, int LA>
 __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_steps_kernel(const KernelArgs k0, int nsteps, int rotate) {
-  __shared__ Np8Lds<NLEV, TPW, false, false, true> lds;
+  __shared__ Np8Lds<NLEV, TPW, false, false, true, true> lds;
   if (element_of_block(k0, blockIdx.x) < 0) return;
   int n0 = k0.n0, np1 = k0.np1, nm1 = k0.nm1;
   Np8Carry<TPW> cy;  // handed from call to call
@@ -478,8 +480,9 @@ __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_steps_kernel(c
     caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, 0>(args(), lds, &cy, nsteps == 1, nsteps <= 3);
     for (int s = 1; s < nsteps; ++s) {
       rotate_levels();
-      lds_barrier();  // the next call re-uses the wave totals: everybody is done with them
-      caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, 2>(args(), lds, &cy, s == nsteps - 1, s >= nsteps - 3);
+      // (no barrier: the only LDS data a wave reads from other waves are the wave totals, and alternate calls use
+      // alternate sets — see caar_np4_steps.hip)
+      caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, false, false, false, false, true, LA, true, 2>(args(), lds, &cy, s == nsteps - 1, s >= nsteps - 3, s & 1);
     }
   } else {
     for (int s = 0; s < nsteps; ++s) {
