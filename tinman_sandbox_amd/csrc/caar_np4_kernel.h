@@ -202,13 +202,20 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   const bool last_live = !UNEVEN || w < FULL;                                    // ... and whether it owns TPW tiles
   const int ntile = last_live ? TPW : TPW - 1;
   auto tile_live = [&](int r) { return !UNEVEN || r < TPW - 1 || last_live; };
-  auto live_row = [&](int r) { return !RAGGED || ((tile0 + r) * 4 + sub) < NLEV; };
+  // Tile numbers, spelled for the even shapes exactly as before this option existed (through a named variable the
+  // compiler schedules the headline kernels differently: measured 1 % slower)
+#define CAAR_TILE0 (UNEVEN ? tile0 : w * TPW)
+#define CAAR_TILE(r) (UNEVEN ? tile0 + (r) : w * TPW + (r))
+#define CAAR_TILE_END (UNEVEN ? tile0 + ntile : w * TPW + TPW)
+#define CAAR_LIVE(r) (UNEVEN ? tile_live(r) : live_row(r))  // (UNEVEN shapes have no ragged last tile)
+  auto live_row = [&](int r) { return !RAGGED || (CAAR_TILE(r) * 4 + sub) < NLEV; };
   // Addressing: every field pointer below is wave-uniform (element, time level and this
   // wave's first tile folded in: an SGPR pair) and is indexed by `r * 64 + ulane` with r
   // a compile-time tile number and ulane an UNSIGNED lane id, so each access is one
   // global_load/store with scalar base, one shared 32-bit lane offset and an immediate.
   const unsigned ulane = kNp4Mfma ? sub * 16 + pt : lane;  // this lane's offset inside a tile of the layout [lev][a][b]
-  const size_t wbase = (size_t)tile0 * 64;  // first point of this wave's tiles inside a field block
+  // (the even shapes keep the expression they always had: the headline kernels' code must not change with this option)
+  const size_t wbase = UNEVEN ? (size_t)tile0 * 64 : (size_t)w * (TPW * 64);  // first point of this wave's tiles inside a field block
 
   long long ie_s = PERSIST ? (blockIdx.x < (unsigned)k.nelem ? (long long)k.nets + blockIdx.x : -1)
                            : element_of_block(k, blockIdx.x);
@@ -227,7 +234,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
 #pragma unroll
     for (int r = 0; r < TPW; ++r) {
       x.dp[r] = x.u[r] = x.v[r] = x.T[r] = x.q[r] = 0.0;
-      if (live_row(r) && tile_live(r)) {
+      if (CAAR_LIVE(r)) {
         x.dp[r] = stream_load<SNT>(dp_n0 + r * 64 + ulane);
         const dbl2 uv = stream_load<SNT>(v_n0 + r * 64 + ulane);
         x.u[r] = uv.x;
@@ -258,7 +265,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   N0In& in = STEPS ? *carry : in_local;
   if (STEPS && carry_valid) {
     if (CARRY_LDS && (carry_flags & 4)) {
-      const lds_cptr cq = lds_reread_ptr(&lds.carry[4][0] + (size_t)tile0 * 64 + lane);
+      const lds_cptr cq = lds_reread_ptr(&lds.carry[4][0] + (UNEVEN ? (size_t)tile0 * 64 : (size_t)w * (TPW * 64)) + lane);
 #pragma unroll
       for (int r = 0; r < TPW; ++r) {
         in.q[r] = 0.0;
@@ -279,7 +286,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     if (!(carry_flags & 4)) {  // first call: the tracer block does not change from call to call (qn0 is fixed)
 #pragma unroll
       for (int r = 0; r < TPW; ++r)
-        if (tile_live(r)) lds.carry[4][(tile0 + r) * 64 + lane] = in.q[r];
+        if (tile_live(r)) lds.carry[4][CAAR_TILE(r) * 64 + lane] = in.q[r];
     }
   }
   double geo_reg = 0.0;
@@ -322,7 +329,6 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     double* __restrict__ eta = k.eta_dot_dpdn + ie * (BLK + PP) + wbase;
     double* __restrict__ eta_last = k.eta_dot_dpdn + ie * (BLK + PP) + BLK;
 
-    const double eta_zero = k.eta_ave_w * 0.0;  // eta_dot_dpdn_tmp == 0 (P:22,172): vertically Lagrangian
     // A later call of a steady step loop: the previous call already added eta_ave_w * 0 to this element's eta_dot_dpdn, and
     // x + 0 is a fixed point after one application (it only turns -0 into +0) — unless eta_ave_w * 0 is a NaN, and then
     // the host does not take the step loop (caar_abi.hip try_fused_steps).  The read-modify-write that changes nothing is
@@ -336,7 +342,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     auto load_tile = [&](int r) {
       const unsigned off = r * 64 + ulane;
       TileIn x = {};
-      if (!live_row(r) || !tile_live(r)) return x;
+      if (!CAAR_LIVE(r)) return x;
       if (CARRY_LDS && (carry_flags & 2)) {
         // the previous call parked its n0 state (this call's nm1) in LDS: it is read where it is used, not a tile ahead
         // (LDS latency needs no prefetch, and four values fewer are live per tile in flight)
@@ -346,7 +352,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
       }
       if (CARRY_LDS >= 2 && (carry_flags & 8)) {  // the previous call left the accumulators (2: and pecnd) in LDS
-        const lds_cptr ca = lds_reread_ptr(&lds.carry[CARRY_LDS >= 2 ? 5 : 0][0] + (tile0 + r) * 64 + lane);
+        const lds_cptr ca = lds_reread_ptr(&lds.carry[CARRY_LDS >= 2 ? 5 : 0][0] + CAAR_TILE(r) * 64 + lane);
         constexpr int Q = NT_MAX * 64;
         x.vn0.x = ca[0];
         x.vn0.y = ca[Q];
@@ -401,8 +407,10 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     double divdp[TPW], Tv[TPW], ex_dp[TPW], ex_div[TPW];
 #pragma unroll
     for (int r = 0; r < TPW; ++r) {
-      if (!tile_live(r)) continue;  // (wave-uniform)
-      const int t = tile0 + r;
+      if constexpr (UNEVEN) {
+        if (!tile_live(r)) continue;  // (wave-uniform)
+      }
+      const int t = CAAR_TILE(r);
       divdp[r] = divergence_sphere(c, Dinv, metdet, rmetdet, rrearth, u[r] * dp[r], v[r] * dp[r]);  // P:114-121
       Tv[r] = MOIST ? T[r] * (1.0 + k.rv_over_rd_m1 * (q[r] * recip(dp[r]))) : T[r];               // P:135,150-151
       if (RAGGED && !live_row(r)) Tv[r] = 0.0;  // dead row: dp == 0 made the line above NaN
@@ -426,14 +434,16 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     double sdot_sum = 0.0;  // VADV: column total of divdp (X:237)
     {
       double base_dp = 0.0, base_div = 0.0;
-      for (int t2 = 0; t2 < tile0; ++t2) {  // tiles above this wave's first tile (wave-uniform trip count)
+      for (int t2 = 0; t2 < CAAR_TILE0; ++t2) {  // tiles above this wave's first tile (wave-uniform trip count)
         base_dp += s_tot_dp[t2 * PP + pt];
         base_div += s_tot_div[t2 * PP + pt];
       }
 #pragma unroll
       for (int r = 0; r < TPW; ++r) {
-        if (!tile_live(r)) continue;
-        const int t = tile0 + r;
+        if constexpr (UNEVEN) {
+          if (!tile_live(r)) continue;
+        }
+        const int t = CAAR_TILE(r);
         p[r] = (k.p_top + (base_dp + ex_dp[r])) + 0.5 * dp[r];  // P:84,94-96 in closed form
         suml[r] = base_div + ex_div[r];                          // P:327,339: sum of divdp above
         rp[r] = recip(p[r]);
@@ -454,7 +464,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         }
       }
       if (VADV) {
-        for (int t2 = tile0 + ntile; t2 < NT; ++t2) base_div += s_tot_div[t2 * PP + pt];
+        for (int t2 = CAAR_TILE_END; t2 < NT; ++t2) base_div += s_tot_div[t2 * PP + pt];
         sdot_sum = base_div;
       }
     }
@@ -490,20 +500,23 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     const double fcor = s_geo[G_FCOR + pt];
     const double spheremp = s_geo[G_SPHEREMP + pt];
     const double phis = s_geo[G_PHIS + pt];
+    const double eta_zero = k.eta_ave_w * 0.0;  // eta_dot_dpdn_tmp == 0 (P:22,172): vertically Lagrangian
 
     double below = 0.0;  // hydrostatic sum over the tiles below this wave's last tile
-    for (int t2 = NT - 1; t2 > tile0 + ntile - 1; --t2) below += s_tot_ht[t2 * PP + pt];
+    for (int t2 = NT - 1; t2 > CAAR_TILE_END - 1; --t2) below += s_tot_ht[t2 * PP + pt];
 
 #pragma unroll
     for (int rr = 0; rr < TPW; ++rr) {
       const int r = TPW - 1 - rr;  // bottom tile of the wave first: `below` accumulates upwards
-      const int t = tile0 + r;
+      const int t = CAAR_TILE(r);
       const unsigned off = r * 64 + ulane;
       TileIn nxt = cur;
       if (r > 0) nxt = PF ? pre[r - 1] : load_tile(r - 1);
-      if (!tile_live(r)) {  // (wave-uniform; only r == TPW - 1 of an UNEVEN shape)
-        cur = nxt;
-        continue;
+      if constexpr (UNEVEN) {
+        if (!tile_live(r)) {  // (wave-uniform; only r == TPW - 1)
+          cur = nxt;
+          continue;
+        }
       }
       double p_r, suml_r, exht_r, divdp_r, Tv_r;  // this tile's scan results (registers, or parked in LDS)
       if constexpr (PARK == 0) {
@@ -661,6 +674,11 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     par ^= 1;
   }
 }
+
+#undef CAAR_TILE0
+#undef CAAR_TILE
+#undef CAAR_TILE_END
+#undef CAAR_LIVE
 
 // The kernel.  POL = cache policy of the element arrays' loads and stores:
 //   1  non-temporal: every array is touched once per launch, nothing is worth keeping (+0.4..5 % over 0);
