@@ -57,6 +57,9 @@ static int cu_count() {
 // VTPW/VMINW/VPF/VPARK: the launch shape of the Eulerian (rsplit == 0) form, which holds more live values per
 // level: the two-workgroup shapes need part of them parked in LDS (VPARK; bit 32 re-reads u, v, T from the column
 // copy the vertical advection keeps there anyway).  tools/eulerian_bench.py, tools/probes/eulerian_variants.py.
+// NLEV=72: FOUR waves with 5, 5, 4, 4 tiles (VTPW = 5; caar_np4_kernel.h UNEVEN): the Eulerian form is heavy on instruction
+// issue, and two 3-wave workgroups load a CU's four SIMDs 2, 2, 1, 1 where two 4-wave ones load them evenly: 76.8 -> 79.9-80.3 %
+// (profiles/r03/eulerian_bench_4w.log; five tiles also fit 229 registers instead of 253).
 template <int NLEV, int TPW, int MINW, int POL, int PF = 0, int PERSIST_WG_PER_CU = 0, bool ETA_COND = false,
           int VTPW = TPW, int VMINW = MINW, int VPF = PF, int PARK = 0, int VPARK = 0>
 static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
@@ -68,7 +71,7 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
     if (grid > num_elems) grid = num_elems;
   }
   if (k.vadv) {  // rsplit == 0: the plain (non-persistent, unconditional eta store) form
-    constexpr int VTHREADS = (NLEV + 3) / 4 / VTPW * 64;
+    constexpr int VTHREADS = ((NLEV + 3) / 4 + VTPW - 1) / VTPW * 64;
     if (PERSIST) grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
     if (k.qn0 >= 0)
       hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, true, POL, VPF, false, false, true, 8, VPARK>), dim3(grid), dim3(VTHREADS), 0, stream, k);
@@ -89,13 +92,13 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
-    {"caar_np4_kernel<72, 6, 1, true, 2, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU), hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<72, 6, 1, 2, 0, 0, false, 6, 2, 0, 0, 43>, true, launch_np4_steps_72_auto},
-    {"caar_np4_kernel<72, 6, 1, true, 1, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU), nt (all streaming), update loads one tile ahead", launch_np4<72, 6, 1, true, 0, 0, false, 6, 2, 0, 0, 43>, false, launch_np4_steps_72_1},
+    {"caar_np4_kernel<72, 6, 1, true, 2, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU), hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<72, 6, 1, 2, 0, 0, false, 5, 2, 0, 0, 43>, true, launch_np4_steps_72_auto},
+    {"caar_np4_kernel<72, 6, 1, true, 1, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU), nt (all streaming), update loads one tile ahead", launch_np4<72, 6, 1, true, 0, 0, false, 5, 2, 0, 0, 43>, false, launch_np4_steps_72_1},
     {"caar_np4_kernel<72, 2, 1, true, 2, 1, false, false, false, 8, 0>", "9 waves x 2 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<72, 2, 1, 2, 1, 0, false, 3, 2, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, false, false, 8, 0>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, true, false, 8, 0>", "9 waves x 2 tiles, nt; eta_dot_dpdn stored only where its bits change (skips the no-op write-back: NOT the contract traffic)", launch_np4<72, 2, 1, true, 1, 0, true, 3, 2, 0>},
     {"caar_np4_kernel<72, 3, 2, true, 1, 1, true, false, false, 8, 0>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt", launch_np4<72, 3, 2, true, 1, 1>},
-    {"caar_np4_kernel<72, 6, 1, true, 0, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU), default cache policy (nothing streams: what a fused multi-step launch wants)", launch_np4<72, 6, 1, 0, 0, 0, false, 6, 2, 0, 0, 43>, true, launch_np4_steps_72_0},
+    {"caar_np4_kernel<72, 6, 1, true, 0, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU), default cache policy (nothing streams: what a fused multi-step launch wants)", launch_np4<72, 6, 1, 0, 0, 0, false, 5, 2, 0, 0, 43>, true, launch_np4_steps_72_0},
 };
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 

@@ -174,7 +174,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   const int BLK = NLEV * PP;           // doubles in one scalar field block
   static_assert(!WAVES || !DYN, "WAVES: compile-time level counts only");
   static_assert(DYN || (FULL >= 1 && FULL <= WAVES_T), "tile decomposition");
-  static_assert(!UNEVEN || (TPW >= 2 && !PERSIST && !VADV && NLEV_T % 4 == 0), "uneven tile counts: plain Lagrangian form");
+  static_assert(!UNEVEN || (TPW >= 2 && !PERSIST && NLEV_T % 4 == 0), "uneven tile counts: non-persistent form, level count a multiple of 4");
   static_assert(!RAGGED || !PERSIST, "ragged level counts: non-persistent form only");
   static_assert(!VADV || (!PERSIST && !ETA_COND), "Eulerian branch: plain form only");
   static_assert(PARK == 0 || (!RAGGED && !PERSIST), "PARK: non-persistent form, level count a multiple of 4");
