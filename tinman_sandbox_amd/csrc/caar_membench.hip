@@ -364,7 +364,7 @@ hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, i
       case 18: hipLaunchKernelGGL((traffic_skeleton_np4<72, 1, 1, 1, true, 16, 6>), dim3(num_elems * 3), dim3(384), 0, s, k); break;
       case 19: hipLaunchKernelGGL((traffic_skeleton_np4<72, 2, 1, 1, true, 16, 3>), dim3(num_elems * 3), dim3(192), 0, s, k); break;
       case 20: hipLaunchKernelGGL((traffic_skeleton_np4<72, 1, 1, 1, false, 16, 1>), dim3(num_elems * 18), dim3(64), 0, s, k); break;
-      case 22: skel<72, 6, 1, 1, true>(k, num_elems, s); break;   // the default kernel's launch shape (3 waves x 6 tiles), nt
+      case 22: skel<72, 6, 1, 1, true>(k, num_elems, s); break;   // the launch shape of the default kernel of rounds 2-3 (3 waves x 6 tiles), nt
       // the same shape with each output array's stores issued as one 3 KiB (u, v: 6 KiB) burst per wave (23) and the loads
       // array-major too (24); 25/26: the same two at 2 waves x 9 tiles (4.5 / 9 KiB bursts)
       case 23: hipLaunchKernelGGL((traffic_skeleton_np4<72, 6, 1, 1, true, 16, 0, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(192), 0, s, k); break;

@@ -21,9 +21,10 @@
 //   * every array is streamed exactly once per launch (non-temporal loads/stores; measured HBM-side traffic =
 //     algorithmic bytes x1.0002), except that the default kernels keep the three read-modify-write accumulators of
 //     part of the elements in the 256 MB Infinity Cache between calls (POL = 2).
-//   * the default launch shapes put TWO workgroups (two elements in different phases) on a CU: NLEV=72 3 waves x 6
-//     tiles (253 VGPRs), NLEV=128 4 waves x 8 tiles with four scan results parked in LDS (PARK).  With the cache
-//     window that is worth 76 -> 83 % of the HBM peak at NLEV=72.
+//   * the default launch shapes put TWO workgroups of FOUR waves (two elements in different phases, one wave of each on
+//     every SIMD of the CU) on a CU: NLEV=72 4 waves owning 5, 5, 4, 4 of the 18 tiles (240 VGPRs; three-wave workgroups
+//     load the four SIMDs 2, 2, 1, 1), NLEV=128 4 waves x 8 tiles with four scan results parked in LDS (PARK).  With the
+//     cache window that is worth 76 -> 84-85 % of the HBM peak at NLEV=72.
 #include <hip/hip_runtime.h>
 
 #include "caar_np4_kernel.h"
@@ -119,8 +120,8 @@ KernelVariant kNp4Nlev32[] = {
 };
 int kNp4Nlev32Count = sizeof(kNp4Nlev32) / sizeof(kNp4Nlev32[0]);
 KernelVariant kNp4Nlev60[] = {
-    {"caar_np4_kernel<60, 1, 1, true, 2, 1, false, false, false, 8, 0>", "15 waves x 1 tile, room for 1 wave/SIMD, hybrid cache policy", launch_np4<60, 1, 1, 2, 1>},
-    {"caar_np4_kernel<60, 1, 1, true, 1, 1, false, false, false, 8, 0>", "15 waves x 1 tile, room for 1 wave/SIMD, nt", launch_np4<60, 1, 1, true, 1>},
+    {"caar_np4_kernel<60, 4, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 4, 4, 4, 3 tiles (two workgroups per CU), hybrid cache policy", launch_np4<60, 4, 1, 2, 0, 0, false, 4, 2, 0, 0, 43>, true},
+    {"caar_np4_kernel<60, 4, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 4, 4, 4, 3 tiles (two workgroups per CU), nt", launch_np4<60, 4, 1, true, 0, 0, false, 4, 2, 0, 0, 43>},
 };
 int kNp4Nlev60Count = sizeof(kNp4Nlev60) / sizeof(kNp4Nlev60[0]);
 KernelVariant kNp4Nlev64[] = {
@@ -129,13 +130,13 @@ KernelVariant kNp4Nlev64[] = {
 };
 int kNp4Nlev64Count = sizeof(kNp4Nlev64) / sizeof(kNp4Nlev64[0]);
 KernelVariant kNp4Nlev80[] = {
-    {"caar_np4_kernel<80, 2, 1, true, 2, 1, false, false, false, 8, 0>", "10 waves x 2 tiles, room for 1 wave/SIMD, hybrid cache policy", launch_np4<80, 2, 1, 2, 1, 0, false, 4, 2, 0>},
-    {"caar_np4_kernel<80, 2, 1, true, 1, 1, false, false, false, 8, 0>", "10 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<80, 2, 1, true, 1, 0, false, 4, 2, 0>},
+    {"caar_np4_kernel<80, 5, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 5 tiles (two workgroups per CU), hybrid cache policy", launch_np4<80, 5, 1, 2, 0, 0, false, 5, 2, 0, 0, 43>, true},
+    {"caar_np4_kernel<80, 5, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 5 tiles (two workgroups per CU), nt", launch_np4<80, 5, 1, true, 0, 0, false, 5, 2, 0, 0, 43>},
 };
 int kNp4Nlev80Count = sizeof(kNp4Nlev80) / sizeof(kNp4Nlev80[0]);
 KernelVariant kNp4Nlev96[] = {
-    {"caar_np4_kernel<96, 2, 1, true, 2, 1, false, false, false, 8, 0>", "12 waves x 2 tiles, room for 1 wave/SIMD, hybrid cache policy", launch_np4<96, 2, 1, 2, 1>},
-    {"caar_np4_kernel<96, 2, 1, true, 1, 1, false, false, false, 8, 0>", "12 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<96, 2, 1, true, 1>},
+    {"caar_np4_kernel<96, 6, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 6 tiles (two workgroups per CU), hybrid cache policy", launch_np4<96, 6, 1, 2, 0, 0, false, 6, 2, 0, 0, 43>, true},
+    {"caar_np4_kernel<96, 6, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 6 tiles (two workgroups per CU), nt", launch_np4<96, 6, 1, true, 0, 0, false, 6, 2, 0, 0, 43>},
 };
 int kNp4Nlev96Count = sizeof(kNp4Nlev96) / sizeof(kNp4Nlev96[0]);
 // Any other level count up to 256: the kernel with a run-time level count (NLEV_T = 0).
@@ -156,16 +157,21 @@ static hipError_t launch_np4_dyn_shape(const KernelArgs& k, int num_elems, hipSt
 }
 static hipError_t launch_np4_dyn(const KernelArgs& k, int num_elems, hipStream_t stream) {
   if (k.nlev < 2 || k.nlev > 256) return hipErrorInvalidValue;
-  if (k.nlev <= 64) return launch_np4_dyn_shape<2, 8, 1>(k, num_elems, stream);    // <= 8 waves x 2 tiles
-  if (k.nlev <= 128) return launch_np4_dyn_shape<4, 8, 0>(k, num_elems, stream);  // <= 8 waves x 4 tiles
-  return launch_np4_dyn_shape<8, 8, 0>(k, num_elems, stream);                     // <= 8 waves x 8 tiles
+  // FOUR waves where the tiles per wave stay within the registers of this masked form (<= 4; 5 spills 36-52 VGPRs, 6
+  // 70-105): workgroups of four waves land one wave on every SIMD of a CU, other counts load the SIMDs unevenly
+  // (tools/probes/simd_placement_probe.hip)
+  const int tiles = (k.nlev + 3) / 4;
+  if (tiles <= 8) return launch_np4_dyn_shape<2, 8, 1>(k, num_elems, stream);    // <= 4 waves x 2 tiles
+  if (tiles <= 12) return launch_np4_dyn_shape<3, 8, 0>(k, num_elems, stream);   // 4 waves x 3
+  if (tiles <= 32) return launch_np4_dyn_shape<4, 8, 0>(k, num_elems, stream);   // 4 waves x 4 up to 64 levels, <= 8 waves x 4 beyond
+  return launch_np4_dyn_shape<8, 8, 0>(k, num_elems, stream);                    // <= 8 waves x 8 tiles
 }
-KernelVariant kNp4NlevAny[] = {{"caar_np4_kernel<0, ...>", "run-time level count (2..256): up to 8 waves x 2/4/8 tiles (12 x 2 measured slower: it spills under the 168-register cap), dead rows masked, nt", launch_np4_dyn}};
+KernelVariant kNp4NlevAny[] = {{"caar_np4_kernel<0, ...>", "run-time level count (2..256): four waves x 2..4 tiles up to 64 levels, up to 8 waves x 4 / 8 tiles beyond, dead rows masked, hybrid cache policy", launch_np4_dyn}};
 
 // level counts that are not a multiple of 4 (last tile partly empty)
 KernelVariant kNp4Nlev26[] = {
-    {"caar_np4_kernel<26, 7, 1, true, 2, 1, false, false, false, 8, 0>", "1 waves x 7 tiles, room for 1 wave/SIMD, hybrid cache policy", launch_np4<26, 7, 1, 2, 1>},
-    {"caar_np4_kernel<26, 7, 1, true, 1, 1, false, false, false, 8, 0>", "1 waves x 7 tiles, room for 1 wave/SIMD, nt", launch_np4<26, 7, 1, true, 1>},
+    {"caar_np4_kernel<26, 2, 1, true, 2, 1, false, false, false, 8, 0>", "4 waves x 2, 2, 2, 1 tiles (the last one half empty), hybrid cache policy", launch_np4<26, 2, 1, 2, 1>, true},
+    {"caar_np4_kernel<26, 2, 1, true, 1, 1, false, false, false, 8, 0>", "4 waves x 2, 2, 2, 1 tiles, nt", launch_np4<26, 2, 1, true, 1>},
 };
 int kNp4Nlev26Count = sizeof(kNp4Nlev26) / sizeof(kNp4Nlev26[0]);
 KernelVariant kNp4Nlev30[] = {

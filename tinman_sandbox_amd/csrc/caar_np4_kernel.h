@@ -122,8 +122,8 @@ struct Np4Lds {
 // PARK: the five per-point values that live from the scans to the last phase (p, divdp prefix, hydrostatic in-tile suffix,
 // divdp, T_v) wait in LDS instead of registers (10 VGPRs per tile): lets a fat shape (few waves x many tiles) stay within
 // 256 registers, i.e. two workgroups per CU, where the level count makes the tiles-per-wave large (NLEV=128: 4 waves x 8)
-// or the form holds more per level (Eulerian, NLEV=72: 3 waves x 6 with p, divdp prefix, divdp parked and u, v, T re-read from
-// the column copy).  The re-reads go through lds_reread_ptr (plain ds_read_b64): near free, 82.9 % against 83.6 % unparked at
+// or the form holds more per level (Eulerian, NLEV=72: 4 waves x 5, 5, 4, 4 with p, divdp prefix, divdp parked and u, v, T re-read
+// from the column copy).  The re-reads go through lds_reread_ptr (plain ds_read_b64): near free, 82.9 % against 83.6 % unparked at
 // NLEV=72.  (Round 2 first had them as `volatile` generic loads = flat_load sc0 sc1 + s_waitcnt vmcnt(0), which drained the
 // global loads in flight at every parked read: 75.4 %.)
 // The n0 inputs of a wave's tiles (dp3d, u, v, T at time level n0; the tracer mass Qdp).  The step loop
@@ -174,7 +174,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   const int BLK = NLEV * PP;           // doubles in one scalar field block
   static_assert(!WAVES || !DYN, "WAVES: compile-time level counts only");
   static_assert(DYN || (FULL >= 1 && FULL <= WAVES_T), "tile decomposition");
-  static_assert(!UNEVEN || (TPW >= 2 && !PERSIST && NLEV_T % 4 == 0), "uneven tile counts: non-persistent form, level count a multiple of 4");
+  static_assert(!UNEVEN || (TPW >= 2 && !PERSIST), "uneven tile counts: non-persistent form");
   static_assert(!RAGGED || !PERSIST, "ragged level counts: non-persistent form only");
   static_assert(!VADV || (!PERSIST && !ETA_COND), "Eulerian branch: plain form only");
   static_assert(PARK == 0 || (!RAGGED && !PERSIST), "PARK: non-persistent form, level count a multiple of 4");
@@ -207,7 +207,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
 #define CAAR_TILE0 (UNEVEN ? tile0 : w * TPW)
 #define CAAR_TILE(r) (UNEVEN ? tile0 + (r) : w * TPW + (r))
 #define CAAR_TILE_END (UNEVEN ? tile0 + ntile : w * TPW + TPW)
-#define CAAR_LIVE(r) (UNEVEN ? tile_live(r) : live_row(r))  // (UNEVEN shapes have no ragged last tile)
+#define CAAR_LIVE(r) (UNEVEN ? (tile_live(r) && live_row(r)) : live_row(r))
   auto live_row = [&](int r) { return !RAGGED || (CAAR_TILE(r) * 4 + sub) < NLEV; };
   // Addressing: every field pointer below is wave-uniform (element, time level and this
   // wave's first tile folded in: an SGPR pair) and is indexed by `r * 64 + ulane` with r

@@ -10,18 +10,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinman_sandbox_amd as tsa  # noqa: E402
 
 lib = tsa.library().lib
-for nlev in (20, 26, 40, 50, 64, 70, 72, 90, 100, 128, 160, 200, 256):
+for nlev in (20, 26, 32, 40, 50, 60, 64, 70, 72, 80, 90, 96, 100, 128, 160, 200, 256):
     E = max(1000, int(10000 * 72 / nlev))
     data = tsa.TestData().init_data(E, 4, nlev, device="cuda")
-    for _ in range(3):
+    for _ in range(80):  # past the ramp of a fresh allocation (DESIGN.md section 5 "Cold start")
         tsa.compute_and_apply_rhs(data)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(20):
+    for _ in range(40):
         tsa.compute_and_apply_rhs(data)
     b.record()
     torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / 20
+    ms = a.elapsed_time(b) / 40
     byts = tsa.algorithmic_bytes(4, nlev) * E
     print("nlev=%3d E=%6d  %.4f ms  %5.0f GB/s (%.1f%% of 8 TB/s)  %s" % (
         nlev, E, ms, byts / ms / 1e6, byts / ms / 8e7, lib.caar_kernel_name(4, nlev).decode()), flush=True)
