@@ -33,10 +33,8 @@ namespace caar {
 
 // caar_np4_steps.hip: nsteps calls as one launch, per (NLEV, cache policy)
 #define CAAR_STEPS_DECL(NLEV, POL) hipError_t launch_np4_steps_##NLEV##_##POL(const KernelArgs&, int, int, int, hipStream_t)
-CAAR_STEPS_DECL(72, 2);
 CAAR_STEPS_DECL(72, 1);
 CAAR_STEPS_DECL(72, 0);
-CAAR_STEPS_DECL(128, 2);
 CAAR_STEPS_DECL(128, 1);
 CAAR_STEPS_DECL(128, 0);
 #undef CAAR_STEPS_DECL

@@ -13,9 +13,8 @@ namespace caar {
 // nsteps calls instead of once per call, and from the second call on the element's arrays are still in the L2 / Infinity
 // Cache of the XCD that wrote them (POL = 0: default cache policy; ~95 MB in flight over the chip).  Each call is the same
 // code as caar_np4_kernel's (caar_np4_element): bit-identical to nsteps single launches.
-// The loop over the calls for one cache policy (SNT / ANT: non-temporal element arrays / accumulators).  The hybrid policy
-// picks one of two such loops per workgroup: with both bodies inside ONE loop the carried state is live across either and
-// the kernel spills 54-71 VGPRs.
+// The loop over the calls for one cache policy (SNT / ANT: non-temporal element arrays / accumulators; the step loops come
+// with the default policy and all-streaming — the hybrid policy is a single call's: it exists to keep data for the NEXT launch).
 // With rotating, distinct time levels (the driver loop) the first call loads everything and every later call takes its n0
 // state from registers and (CARRY_LDS) its nm1 state and tracer block from LDS — two instantiations of the body, the
 // steady one with no n0 / nm1 / Qdp loads at all.  Without rotation, or with aliased time levels, every call loads
@@ -88,12 +87,8 @@ __global__ __launch_bounds__((WAVES ? WAVES : ((NLEV_T + 3) / 4 + TPW - 1) / TPW
   __shared__ Np4Lds<NLEV_T, TPW, false, false, 8, PARK, CARRY_LDS> lds;
   const long long ie_s = element_of_block(k0, blockIdx.x);
   if (ie_s < 0) return;
-  if constexpr (POL == 2) {
-    if (element_is_cached(k0, ie_s - k0.nets)) np4_step_loop<NLEV_T, TPW, MINW, MOIST, true, false, PF, PARK, CARRY_LDS, WAVES>(k0, nsteps, rotate, lds);
-    else np4_step_loop<NLEV_T, TPW, MINW, MOIST, true, true, PF, PARK, CARRY_LDS, WAVES>(k0, nsteps, rotate, lds);
-  } else {
-    np4_step_loop<NLEV_T, TPW, MINW, MOIST, POL == 1, POL == 1, PF, PARK, CARRY_LDS, WAVES>(k0, nsteps, rotate, lds);
-  }
+  static_assert(POL == 0 || POL == 1, "step loops: default cache policy or all-streaming (the hybrid policy is a single call's)");
+  np4_step_loop<NLEV_T, TPW, MINW, MOIST, POL == 1, POL == 1, PF, PARK, CARRY_LDS, WAVES>(k0, nsteps, rotate, lds);
 }
 
 template <int NLEV, int TPW, int MINW, int POL, int PF, int PARK, int CARRY_LDS = (NLEV <= 72 ? 1 : 0), int WAVES = 0>
@@ -117,10 +112,8 @@ static hipError_t launch_np4_steps(const KernelArgs& k, int num_elems, int nstep
 // instruction issue, and two 3 x 6 workgroups put 2, 2, 1, 1 waves on a CU's four SIMDs (12 tiles per pair of elements on
 // the busiest) where two 4-wave ones put one wave each on every SIMD (9-10): 0.134 against 0.151 ms per call at 10 000
 // elements (profiles/r03/steps_bench_72_4w.log, simd_placement_probe.log).  Nothing parked: five tiles fit the registers.
-CAAR_STEPS(72, 5, 2, 2, 0, 0)
 CAAR_STEPS(72, 5, 2, 1, 0, 0)
 CAAR_STEPS(72, 5, 2, 0, 0, 0)
-CAAR_STEPS(128, 8, 2, 2, 0, 27)
 CAAR_STEPS(128, 8, 2, 1, 0, 27)
 CAAR_STEPS(128, 8, 2, 0, 0, 27)
 #undef CAAR_STEPS
