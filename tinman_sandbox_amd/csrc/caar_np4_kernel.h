@@ -16,18 +16,22 @@ namespace caar {
 // Lanes l, l+16, l+32, l+48 hold levels 4t..4t+3 of one GLL point.
 __device__ __forceinline__ double shfl_abs(double x, int src_lane) { return __shfl(x, src_lane, 64); }
 
-// Lane -> (level inside the tile, GLL point).  CAAR_NP4_MFMA = 0 (default): lane = 16lev + 4a + b, the Dvv contractions
-// inside DPP rows.  1: lane = 16a + 4lev + b, the operand / result layout of v_mfma_f64_4x4x4 (caar_np4_ops.h "MFMA
-// form"): the contractions of the four levels of a tile are ONE matrix instruction each.  Either way a wave covers the
-// same 64 consecutive doubles of a field block; LSTEP is the lane distance between consecutive levels (the in-tile scans).
-// Measured A/B, two builds alternating on one box (profiles/r03/kbench_mfma_vs_dpp.log, steps_bench_72_mfma.log): the
-// MFMA form has ~14 fewer VGPRs and makes the step loop 12 % faster (0.161 against 0.180 ms per call at 10 000 elements:
-// that loop is close to VALU-bound), but the memory-bound single call 0.5-1 % SLOWER (82.6-82.7 % against 83.1-83.2 % with
-// the cache window, 74.3 against 75.2 % all-streaming: lanes of a wave address their 512 bytes in 32-byte groups instead
-// of in order).  The single call is the headline, and the step loop has to stay bit-identical to it, so the whole NP=4
-// family uses the DPP form; all 171 GPU tests pass with either.
+// Lane -> (level inside the tile, GLL point).  CAAR_NP4_MFMA = 1 (default): lane = 16a + 4lev + b, the operand / result
+// layout of v_mfma_f64_4x4x4 (caar_np4_ops.h "MFMA form"): the contractions of the four levels of a tile are ONE matrix
+// instruction each.  0: lane = 16lev + 4a + b, the Dvv contractions inside DPP rows (the form of rounds 1-3).  Either way a
+// wave covers the same 64 consecutive doubles of a field block; LSTEP is the lane distance between consecutive levels (the
+// in-tile scans).  The whole NP=4 family uses ONE form, so that every kernel of it — launch shapes, cache policies, the
+// step loops — stays bit-identical to every other.
+// Measured A/B, two builds alternating on one box.  With the 3 x 6 workgroups of rounds 2-3 the MFMA form made the step
+// loop 12 % faster but the memory-bound single call 0.5-1 % SLOWER (lanes of a wave address their 512 bytes in 32-byte
+// groups instead of in order; profiles/r03/kbench_mfma_vs_dpp.log), and the DPP form stayed.  With the four-wave workgroups
+// (one wave on every SIMD) it is ahead everywhere: headline 85.2-85.4 against 84.4-84.9 %, all-streaming 76.0-76.2 against
+// 75.5-75.7, step loop 0.123 against 0.131 ms per call (NLEV=128: 0.296 against 0.319), the Eulerian form of NLEV=128 +1
+// point, the run-time-level-count kernel 84.8 against 61.6 % at 20 levels, 57-65 against 38-50 % above 128 (its masked
+// form is short of registers and the MFMA form needs ~14 fewer); profiles/r03/kbench_mfma_vs_dpp_4w.log,
+// steps_bench_mfma_vs_dpp_4w.log, mfma_vs_dpp_other.log.  All GPU tests pass with either.
 #ifndef CAAR_NP4_MFMA
-#define CAAR_NP4_MFMA 0
+#define CAAR_NP4_MFMA 1
 #endif
 constexpr bool kNp4Mfma = CAAR_NP4_MFMA != 0;
 constexpr int LSTEP = kNp4Mfma ? 4 : 16;
