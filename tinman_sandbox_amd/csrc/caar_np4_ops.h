@@ -1,10 +1,11 @@
-// caar_np4_ops.h — the three sphere operators for NP=4 on one 16-lane DPP row.
+// caar_np4_ops.h — the three sphere operators for NP=4, in two forms.
 //
 // gradient_sphere / divergence_sphere / vorticity_sphere of the reference
-// (compute_and_apply_rhs_test/cxx/pointers_only/sphere_operators.cpp:9-129, cited as S:)
-// for lane = a*4 + b of a 16-lane row holding one level of one element.  Used by the
-// fused kernel (caar_np4.hip) and by the stand-alone operator entry point
-// (caar_operators.hip, caar_sphere_operator).
+// (compute_and_apply_rhs_test/cxx/pointers_only/sphere_operators.cpp:9-129, cited as S:):
+//   * DPP form: lane = a*4 + b of a 16-lane row holding one level of one element (the simple stand-alone operators,
+//     caar_operators.hip / caar_operators_ex.hip; the fused kernels in the -DCAAR_NP4_MFMA=0 build);
+//   * MFMA form (second half of this file): the four levels of a tile through one v_mfma_f64_4x4x4 per contraction —
+//     the fused kernels (caar_np4_kernel.h, default) and the composite operators.
 #ifndef CAAR_NP4_OPS_H
 #define CAAR_NP4_OPS_H
 
@@ -94,9 +95,9 @@ __device__ __forceinline__ RowCoef make_row_coef(const double* dvv, int lane) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// MFMA form of the NP=4 contractions, for kernels that are bound by VALU issue rather than by memory (the composite
-// operators of caar_operators_ex.hip: 2-6 contraction pairs per point for 1-2 KiB of traffic per tile; the DPP form
-// costs 14 cross-lane moves + 8 FMAs per pair).  v_mfma_f64_4x4x4_4b_f64 multiplies four independent 4x4 blocks per
+// MFMA form of the NP=4 contractions: what the fused kernels use by default (caar_np4_kernel.h CAAR_NP4_MFMA) and what
+// the composite operators of caar_operators_ex.hip need (2-6 contraction pairs per point for 1-2 KiB of traffic per tile:
+// bound by VALU issue in the DPP form, which costs 14 cross-lane moves + 8 FMAs per pair).  v_mfma_f64_4x4x4_4b_f64 multiplies four independent 4x4 blocks per
 // issue: one block = one LEVEL of the tile, so one issue is one contraction of all four levels a wave holds.
 // Operand layouts (measured: tools/probes/mfma_f64_probe.hip, profiles/r02/mfma_probe.log):
 //     A[blk][i][k] in lane 16k + 4blk + i,   B[blk][k][j] in lane 16k + 4blk + j,   D[blk][i][j] in lane 16i + 4blk + j.
