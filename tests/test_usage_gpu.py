@@ -320,7 +320,7 @@ def test_cache_window_changes_nothing_but_speed(nlev, rsplit):
                 assert np.array_equal(got[n], ref[n]), (window, n)
         assert lib.caar_set_cache_window(-1) != 0
     finally:
-        lib.caar_set_cache_window(192 << 20)
+        lib.caar_set_cache_window(224 << 20)
 
 
 def test_arrays_placed_for_bandwidth_compute_the_same(oracle, monkeypatch):

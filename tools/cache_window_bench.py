@@ -34,7 +34,7 @@ for nlev, E in ((72, 10000), (128, 12500)):
         for mb in (0, 64, 128, 160, 176, 192, 208, 224, 256, 320):
             lib.caar_set_cache_window(mb << 20)
             row.append("%dMB %.4f" % (mb, timed(data)))
-        lib.caar_set_cache_window(192 << 20)
+        lib.caar_set_cache_window(224 << 20)
         print("nlev=%d E=%d  ms per call: " % (nlev, E) + " | ".join(row), flush=True)
     del data
     torch.cuda.empty_cache()

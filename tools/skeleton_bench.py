@@ -47,7 +47,7 @@ for rnd in range(a.rounds):
     lib.caar_set_cache_window(0)
     rows.setdefault("kernel (default variant, all streaming)", []).append(
         balg / timed(lambda: tsa.compute_and_apply_rhs(data, st)) / 1e9)
-    lib.caar_set_cache_window(192 << 20)
+    lib.caar_set_cache_window(224 << 20)
     rows.setdefault("kernel (default variant, hybrid window)", []).append(
         balg / timed(lambda: tsa.compute_and_apply_rhs(data, st)) / 1e9)
     for i in [int(x) for x in a.ids.split(",")]:
