@@ -157,16 +157,19 @@ static hipError_t launch_np4_dyn_shape(const KernelArgs& k, int num_elems, hipSt
 }
 static hipError_t launch_np4_dyn(const KernelArgs& k, int num_elems, hipStream_t stream) {
   if (k.nlev < 2 || k.nlev > 256) return hipErrorInvalidValue;
-  // FOUR waves where the tiles per wave stay within the registers of this masked form (<= 4; 5 spills 36-52 VGPRs, 6
-  // 70-105): workgroups of four waves land one wave on every SIMD of a CU, other counts load the SIMDs unevenly
-  // (tools/probes/simd_placement_probe.hip)
+  // FOUR waves where the tiles per wave stay within the registers of this masked form (<= 6 with the MFMA contractions:
+  // 248 VGPRs, the Eulerian form 34 spilled at 6): workgroups of four waves land one wave on every SIMD of a CU, other
+  // counts load the SIMDs unevenly (tools/probes/simd_placement_probe.hip)
   const int tiles = (k.nlev + 3) / 4;
   if (tiles <= 8) return launch_np4_dyn_shape<2, 8, 1>(k, num_elems, stream);    // <= 4 waves x 2 tiles
   if (tiles <= 12) return launch_np4_dyn_shape<3, 8, 0>(k, num_elems, stream);   // 4 waves x 3
-  if (tiles <= 32) return launch_np4_dyn_shape<4, 8, 0>(k, num_elems, stream);   // 4 waves x 4 up to 64 levels, <= 8 waves x 4 beyond
+  if (tiles <= 16) return launch_np4_dyn_shape<4, 8, 0>(k, num_elems, stream);   // 4 waves x 4
+  if (tiles <= 20) return launch_np4_dyn_shape<5, 8, 0>(k, num_elems, stream);   // 4 waves x 5
+  if (tiles <= 24) return launch_np4_dyn_shape<6, 8, 0>(k, num_elems, stream);   // 4 waves x 6
+  if (tiles <= 32) return launch_np4_dyn_shape<4, 8, 0>(k, num_elems, stream);   // <= 8 waves x 4 tiles
   return launch_np4_dyn_shape<8, 8, 0>(k, num_elems, stream);                    // <= 8 waves x 8 tiles
 }
-KernelVariant kNp4NlevAny[] = {{"caar_np4_kernel<0, ...>", "run-time level count (2..256): four waves x 2..4 tiles up to 64 levels, up to 8 waves x 4 / 8 tiles beyond, dead rows masked, hybrid cache policy", launch_np4_dyn}};
+KernelVariant kNp4NlevAny[] = {{"caar_np4_kernel<0, ...>", "run-time level count (2..256): four waves x 2..6 tiles up to 96 levels, up to 8 waves x 4 / 8 tiles beyond, dead rows masked, hybrid cache policy", launch_np4_dyn}};
 
 // level counts that are not a multiple of 4 (last tile partly empty)
 KernelVariant kNp4Nlev26[] = {
