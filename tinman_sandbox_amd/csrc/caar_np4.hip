@@ -97,7 +97,7 @@ KernelVariant kNp4Nlev72[] = {
     {"caar_np4_kernel<72, 5, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 5, 5, 4, 4 tiles (two workgroups per CU), nt (all streaming), update loads one tile ahead", launch_np4<72, 5, 1, true, 0, 0, false, 5, 2, 0, 0, 43>, false, launch_np4_steps_72_1},
     {"caar_np4_kernel<72, 6, 1, true, 2, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU: 2, 2, 1, 1 waves on the four SIMDs; the default of rounds 2-3), hybrid cache policy, update loads one tile ahead", launch_np4<72, 6, 1, 2, 0, 0, false, 6, 2, 0, 0, 43>, true},
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, false, false, 8, 0>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},
-    {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, true, false, 8, 0>", "9 waves x 2 tiles, nt; eta_dot_dpdn stored only where its bits change (skips the no-op write-back: NOT the contract traffic)", launch_np4<72, 2, 1, true, 1, 0, true, 3, 2, 0>},
+    {"caar_np4_kernel<72, 5, 1, true, 2, 0, false, true, false, 8, 0>", "the default's shape and cache policy; eta_dot_dpdn stored only where its bits change (skips the no-op write-back of the vertically Lagrangian form: NOT the contract traffic, same results)", launch_np4<72, 5, 1, 2, 0, 0, true, 5, 2, 0, 0, 43>, true},
     {"caar_np4_kernel<72, 3, 2, true, 1, 1, true, false, false, 8, 0>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt", launch_np4<72, 3, 2, true, 1, 1>},
     {"caar_np4_kernel<72, 5, 1, true, 0, 0, false, false, false, 8, 0>", "4 waves x 5, 5, 4, 4 tiles (two workgroups per CU), default cache policy (nothing streams: what a fused multi-step launch wants)", launch_np4<72, 5, 1, 0, 0, 0, false, 5, 2, 0, 0, 43>, true, launch_np4_steps_72_0},
 };
