@@ -159,7 +159,12 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
     else if (idx < G_D) src = k.phis + ie * PP + (idx - G_PHIS);
     else if (idx < G_DINV) src = k.D + ie * PP * 4 + (idx - G_D);
     else src = k.Dinv + ie * PP * 4 + (idx - G_DINV);
-    s_geo[idx] = stream_load<SNT>(src);
+    int d = idx;  // D, Dinv: [point][r][c] in memory -> [r*2 + c][point] in LDS (load_m22)
+    if (idx >= G_D) {
+      const int base = idx < G_DINV ? G_D : G_DINV, i = idx - base;
+      d = base + (i & 3) * PP + (i >> 2);
+    }
+    s_geo[d] = stream_load<SNT>(src);
   }
   if (!CARRY_IN) wg_sync();
 

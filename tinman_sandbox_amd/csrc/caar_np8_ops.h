@@ -78,13 +78,17 @@ __device__ __forceinline__ void put_tile(const Ctx& c, int lane, double f) {
 struct M22 {
   double m00, m01, m10, m11;
 };
+// The 2x2 tensors lie in LDS component-major, [r*2 + c][point] (caar_np8.hip stages them that way): the 64 lanes of a
+// wave read 64 consecutive doubles per component.  Point-major (32-byte stride between lanes) every one of these reads —
+// eight per level and lane in the last phase — was an 8-way bank conflict: SQ_LDS_BANK_CONFLICT 10 900 cycles per
+// element-call against 4 650 LDS-active ones (profiles/r03/pmc_issue.json).
 template <class Ptr>  // const double* or lds_cptr
 __device__ __forceinline__ M22 load_m22(Ptr g, int pt) {
   M22 m;
-  m.m00 = g[pt * 4 + 0];
-  m.m01 = g[pt * 4 + 1];
-  m.m10 = g[pt * 4 + 2];
-  m.m11 = g[pt * 4 + 3];
+  m.m00 = g[0 * PP + pt];
+  m.m01 = g[1 * PP + pt];
+  m.m10 = g[2 * PP + pt];
+  m.m11 = g[3 * PP + pt];
   return m;
 }
 
