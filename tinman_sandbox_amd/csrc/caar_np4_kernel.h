@@ -201,7 +201,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   const size_t tl = (size_t)k.timelevels;
   // RAGGED (NLEV not a multiple of 4): the rows of the last tile beyond level NLEV-1 are dead:
   // their loads are masked and return 0, they contribute 0 to the three integrals, and they
-  // store nothing.  DPP rows are one level each, so dead rows never feed live ones.
+  // store nothing.  A level is one block of the 4x4x4 MFMA (one DPP row in the DPP build), so dead rows never feed live ones.
   const int tile0 = UNEVEN ? w * (TPW - 1) + (w < FULL ? w : FULL) : w * TPW;  // this wave's first tile (wave-uniform)
   const bool last_live = !UNEVEN || w < FULL;                                    // ... and whether it owns TPW tiles
   const int ntile = last_live ? TPW : TPW - 1;
