@@ -140,7 +140,7 @@ KernelVariant kNp4Nlev96[] = {
 };
 int kNp4Nlev96Count = sizeof(kNp4Nlev96) / sizeof(kNp4Nlev96[0]);
 // Any other level count up to 256: the kernel with a run-time level count (NLEV_T = 0).
-template <int TPW, int MAXW, int PF, int VPF = 0>
+template <int TPW, int MAXW, int PF, int VPF = 0, int PARK = 0>
 static hipError_t launch_np4_dyn_shape(const KernelArgs& k, int num_elems, hipStream_t stream) {
   const int tiles = (k.nlev + 3) / 4, waves = (tiles + TPW - 1) / TPW;
   const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
@@ -150,8 +150,8 @@ static hipError_t launch_np4_dyn_shape(const KernelArgs& k, int num_elems, hipSt
     if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, true, true, VPF, false, false, true, MAXW>), dim3(grid), block, 0, stream, k);
     else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, false, true, VPF, false, false, true, MAXW>), dim3(grid), block, 0, stream, k);
   } else {
-    if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, true, 2, PF, false, false, false, MAXW>), dim3(grid), block, 0, stream, k);
-    else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, false, 2, PF, false, false, false, MAXW>), dim3(grid), block, 0, stream, k);
+    if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, true, 2, PF, false, false, false, MAXW, PARK>), dim3(grid), block, 0, stream, k);
+    else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, false, 2, PF, false, false, false, MAXW, PARK>), dim3(grid), block, 0, stream, k);
   }
   return hipGetLastError();
 }
@@ -166,10 +166,13 @@ static hipError_t launch_np4_dyn(const KernelArgs& k, int num_elems, hipStream_t
   if (tiles <= 16) return launch_np4_dyn_shape<4, 8, 0>(k, num_elems, stream);   // 4 waves x 4
   if (tiles <= 20) return launch_np4_dyn_shape<5, 8, 0>(k, num_elems, stream);   // 4 waves x 5
   if (tiles <= 24) return launch_np4_dyn_shape<6, 8, 0>(k, num_elems, stream);   // 4 waves x 6
-  if (tiles <= 32) return launch_np4_dyn_shape<4, 8, 0>(k, num_elems, stream);   // <= 8 waves x 4 tiles
-  return launch_np4_dyn_shape<8, 8, 0>(k, num_elems, stream);                    // <= 8 waves x 8 tiles
+  if (tiles <= 32 && !k.vadv) return launch_np4_dyn_shape<8, 4, 0, 0, 27>(k, num_elems, stream);  // 4 waves x 8 tiles, scan results parked: two workgroups per CU like the NLEV=128 kernel
+  if (tiles <= 32) return launch_np4_dyn_shape<4, 8, 0>(k, num_elems, stream);   // Eulerian form: <= 8 waves x 4 tiles
+  // beyond 128 levels: <= 8 waves x 8 tiles, one workgroup per CU, p / divdp prefix / divdp / T_v parked in LDS like the
+  // NLEV=128 kernel (157 KB; 231 VGPRs instead of 52-90 spilled)
+  return launch_np4_dyn_shape<8, 8, 0, 0, 27>(k, num_elems, stream);
 }
-KernelVariant kNp4NlevAny[] = {{"caar_np4_kernel<0, ...>", "run-time level count (2..256): four waves x 2..6 tiles up to 96 levels, up to 8 waves x 4 / 8 tiles beyond, dead rows masked, hybrid cache policy", launch_np4_dyn}};
+KernelVariant kNp4NlevAny[] = {{"caar_np4_kernel<0, ...>", "run-time level count (2..256): four waves x 2..6 tiles up to 96 levels, four waves x 8 tiles (scan results parked) up to 128, 8 waves x 8 (parked) beyond, dead rows masked, hybrid cache policy", launch_np4_dyn}};
 
 // level counts that are not a multiple of 4 (last tile partly empty)
 KernelVariant kNp4Nlev26[] = {

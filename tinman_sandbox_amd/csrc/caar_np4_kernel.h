@@ -181,7 +181,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   static_assert(!UNEVEN || (TPW >= 2 && !PERSIST), "uneven tile counts: non-persistent form");
   static_assert(!RAGGED || !PERSIST, "ragged level counts: non-persistent form only");
   static_assert(!VADV || (!PERSIST && !ETA_COND), "Eulerian branch: plain form only");
-  static_assert(PARK == 0 || (!RAGGED && !PERSIST), "PARK: non-persistent form, level count a multiple of 4");
+  static_assert(PARK == 0 || !PERSIST, "PARK: non-persistent form");  // (ragged / dead rows park garbage nobody reads)
 
   static_assert(G_SIZE == 208, "Np4Lds::geo_buf");
   double* const s_dvv = lds.dvv;

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinman_sandbox_amd as tsa  # noqa: E402
 
 lib = tsa.library().lib
-for nlev in (20, 26, 32, 40, 50, 60, 64, 70, 72, 80, 90, 96, 100, 128, 160, 200, 256):
+for nlev in (20, 26, 32, 40, 50, 60, 64, 70, 72, 80, 90, 96, 100, 112, 128, 160, 200, 256):
     E = max(1000, int(10000 * 72 / nlev))
     data = tsa.TestData().init_data(E, 4, nlev, device="cuda")
     for _ in range(80):  # past the ramp of a fresh allocation (DESIGN.md section 5 "Cold start")
