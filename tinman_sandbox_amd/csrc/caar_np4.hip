@@ -61,6 +61,10 @@ static int cu_count() {
 // NLEV=72: FOUR waves with 5, 5, 4, 4 tiles (VTPW = 5; caar_np4_kernel.h UNEVEN): the Eulerian form is heavy on instruction
 // issue, and two 3-wave workgroups load a CU's four SIMDs 2, 2, 1, 1 where two 4-wave ones load them evenly: 76.8 -> 79.9-80.3 %
 // (profiles/r03/eulerian_bench_4w.log; five tiles also fit 229 registers instead of 253).
+// With the contractions on the matrix cores (~14 registers fewer) five tiles need no parking at all (VPARK = 0: 247 VGPRs,
+// 82.0 against 80.4 % with p / divdp prefix / divdp parked), and NLEV=128 fits its two-workgroup shape at last: 4 waves x 8
+// tiles with ONE scan result (p) parked and u, v, T re-read from the column copy (VPARK = 33: 81.4 KB of LDS, 22 VGPRs
+// spilled) — 77.8 against 72.9 % for 8 waves x 4 tiles, one workgroup per CU (profiles/r03/eulerian_vpark.log).
 template <int NLEV, int TPW, int MINW, int POL, int PF = 0, int PERSIST_WG_PER_CU = 0, bool ETA_COND = false,
           int VTPW = TPW, int VMINW = MINW, int VPF = PF, int PARK = 0, int VPARK = 0>
 static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
@@ -93,22 +97,22 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
-    {"caar_np4_kernel<72, 5, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 5, 5, 4, 4 tiles (two workgroups per CU, one wave of each on every SIMD), hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<72, 5, 1, 2, 0, 0, false, 5, 2, 0, 0, 43>, true, launch_np4_steps_72_auto},
-    {"caar_np4_kernel<72, 5, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 5, 5, 4, 4 tiles (two workgroups per CU), nt (all streaming), update loads one tile ahead", launch_np4<72, 5, 1, true, 0, 0, false, 5, 2, 0, 0, 43>, false, launch_np4_steps_72_1},
+    {"caar_np4_kernel<72, 5, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 5, 5, 4, 4 tiles (two workgroups per CU, one wave of each on every SIMD), hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<72, 5, 1, 2, 0, 0, false, 5, 2, 0, 0, 0>, true, launch_np4_steps_72_auto},
+    {"caar_np4_kernel<72, 5, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 5, 5, 4, 4 tiles (two workgroups per CU), nt (all streaming), update loads one tile ahead", launch_np4<72, 5, 1, true, 0, 0, false, 5, 2, 0, 0, 0>, false, launch_np4_steps_72_1},
     {"caar_np4_kernel<72, 6, 1, true, 2, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU: 2, 2, 1, 1 waves on the four SIMDs; the default of rounds 2-3), hybrid cache policy, update loads one tile ahead", launch_np4<72, 6, 1, 2, 0, 0, false, 6, 2, 0, 0, 43>, true},
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, false, false, 8, 0>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},
-    {"caar_np4_kernel<72, 5, 1, true, 2, 0, false, true, false, 8, 0>", "the default's shape and cache policy; eta_dot_dpdn stored only where its bits change (skips the no-op write-back of the vertically Lagrangian form: NOT the contract traffic, same results)", launch_np4<72, 5, 1, 2, 0, 0, true, 5, 2, 0, 0, 43>, true},
+    {"caar_np4_kernel<72, 5, 1, true, 2, 0, false, true, false, 8, 0>", "the default's shape and cache policy; eta_dot_dpdn stored only where its bits change (skips the no-op write-back of the vertically Lagrangian form: NOT the contract traffic, same results)", launch_np4<72, 5, 1, 2, 0, 0, true, 5, 2, 0, 0, 0>, true},
     {"caar_np4_kernel<72, 3, 2, true, 1, 1, true, false, false, 8, 0>", "persistent (1 workgroup/CU), 6 waves x 3 tiles, nt", launch_np4<72, 3, 2, true, 1, 1>},
-    {"caar_np4_kernel<72, 5, 1, true, 0, 0, false, false, false, 8, 0>", "4 waves x 5, 5, 4, 4 tiles (two workgroups per CU), default cache policy (nothing streams: what a fused multi-step launch wants)", launch_np4<72, 5, 1, 0, 0, 0, false, 5, 2, 0, 0, 43>, true, launch_np4_steps_72_0},
+    {"caar_np4_kernel<72, 5, 1, true, 0, 0, false, false, false, 8, 0>", "4 waves x 5, 5, 4, 4 tiles (two workgroups per CU), default cache policy (nothing streams: what a fused multi-step launch wants)", launch_np4<72, 5, 1, 0, 0, 0, false, 5, 2, 0, 0, 0>, true, launch_np4_steps_72_0},
 };
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
-    {"caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS between the phases, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<128, 8, 2, 2, 0, 0, false, 4, 2, 0, 27, 32>, true, launch_np4_steps_128_auto},
-    {"caar_np4_kernel<128, 8, 2, true, 1, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS, nt (all streaming), update loads one tile ahead", launch_np4<128, 8, 2, true, 0, 0, false, 4, 2, 0, 27, 32>, false, launch_np4_steps_128_1},
-    {"caar_np4_kernel<128, 4, 2, true, 2, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<128, 4, 2, 2, 1, 0, false, 8, 1, 0>},
-    {"caar_np4_kernel<128, 4, 2, true, 1, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 1, 0>},
-    {"caar_np4_kernel<128, 8, 2, true, 0, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), scan results parked in LDS, default cache policy (what a fused multi-step launch wants)", launch_np4<128, 8, 2, 0, 0, 0, false, 4, 2, 0, 27, 32>, true, launch_np4_steps_128_0},
+    {"caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS between the phases, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<128, 8, 2, 2, 0, 0, false, 8, 2, 0, 27, 33>, true, launch_np4_steps_128_auto},
+    {"caar_np4_kernel<128, 8, 2, true, 1, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS, nt (all streaming), update loads one tile ahead", launch_np4<128, 8, 2, true, 0, 0, false, 8, 2, 0, 27, 33>, false, launch_np4_steps_128_1},
+    {"caar_np4_kernel<128, 4, 2, true, 2, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<128, 4, 2, 2, 1, 0, false, 8, 2, 0, 0, 33>},
+    {"caar_np4_kernel<128, 4, 2, true, 1, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 2, 0, 0, 33>},
+    {"caar_np4_kernel<128, 8, 2, true, 0, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), scan results parked in LDS, default cache policy (what a fused multi-step launch wants)", launch_np4<128, 8, 2, 0, 0, 0, false, 8, 2, 0, 27, 33>, true, launch_np4_steps_128_0},
 };
 int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 
@@ -120,8 +124,8 @@ KernelVariant kNp4Nlev32[] = {
 };
 int kNp4Nlev32Count = sizeof(kNp4Nlev32) / sizeof(kNp4Nlev32[0]);
 KernelVariant kNp4Nlev60[] = {
-    {"caar_np4_kernel<60, 4, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 4, 4, 4, 3 tiles (two workgroups per CU), hybrid cache policy", launch_np4<60, 4, 1, 2, 0, 0, false, 4, 2, 0, 0, 43>, true},
-    {"caar_np4_kernel<60, 4, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 4, 4, 4, 3 tiles (two workgroups per CU), nt", launch_np4<60, 4, 1, true, 0, 0, false, 4, 2, 0, 0, 43>},
+    {"caar_np4_kernel<60, 4, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 4, 4, 4, 3 tiles (two workgroups per CU), hybrid cache policy", launch_np4<60, 4, 1, 2, 0, 0, false, 4, 2, 0, 0, 0>, true},
+    {"caar_np4_kernel<60, 4, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 4, 4, 4, 3 tiles (two workgroups per CU), nt", launch_np4<60, 4, 1, true, 0, 0, false, 4, 2, 0, 0, 0>},
 };
 int kNp4Nlev60Count = sizeof(kNp4Nlev60) / sizeof(kNp4Nlev60[0]);
 KernelVariant kNp4Nlev64[] = {
@@ -130,8 +134,8 @@ KernelVariant kNp4Nlev64[] = {
 };
 int kNp4Nlev64Count = sizeof(kNp4Nlev64) / sizeof(kNp4Nlev64[0]);
 KernelVariant kNp4Nlev80[] = {
-    {"caar_np4_kernel<80, 5, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 5 tiles (two workgroups per CU), hybrid cache policy", launch_np4<80, 5, 1, 2, 0, 0, false, 5, 2, 0, 0, 43>, true},
-    {"caar_np4_kernel<80, 5, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 5 tiles (two workgroups per CU), nt", launch_np4<80, 5, 1, true, 0, 0, false, 5, 2, 0, 0, 43>},
+    {"caar_np4_kernel<80, 5, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 5 tiles (two workgroups per CU), hybrid cache policy", launch_np4<80, 5, 1, 2, 0, 0, false, 5, 2, 0, 0, 0>, true},
+    {"caar_np4_kernel<80, 5, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 5 tiles (two workgroups per CU), nt", launch_np4<80, 5, 1, true, 0, 0, false, 5, 2, 0, 0, 0>},
 };
 int kNp4Nlev80Count = sizeof(kNp4Nlev80) / sizeof(kNp4Nlev80[0]);
 KernelVariant kNp4Nlev96[] = {
