@@ -440,7 +440,7 @@ def eulerian_scalars(nlev, **kw):
     return sc
 
 
-@pytest.mark.parametrize("np_,nlev", [(4, 72), (4, 128), (8, 72), (4, 26), (4, 30), (4, 64)])
+@pytest.mark.parametrize("np_,nlev", [(4, 72), (4, 128), (8, 72), (4, 26), (4, 30), (4, 64), (4, 60), (4, 80), (4, 96), (4, 100)])
 def test_eulerian_vertical_coordinate_matches_oracle(oracle, np_, nlev):
     """rsplit == 0: interface mass flux eta_dot_dpdn, vertical advection of T and v, the flux
     divergence in the dp3d update (routine_extracted.F90:224-262,515-517, CaarFunctor.hpp:505-547).

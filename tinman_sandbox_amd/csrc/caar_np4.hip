@@ -139,8 +139,8 @@ KernelVariant kNp4Nlev80[] = {
 };
 int kNp4Nlev80Count = sizeof(kNp4Nlev80) / sizeof(kNp4Nlev80[0]);
 KernelVariant kNp4Nlev96[] = {
-    {"caar_np4_kernel<96, 6, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 6 tiles (two workgroups per CU), hybrid cache policy", launch_np4<96, 6, 1, 2, 0, 0, false, 6, 2, 0, 0, 43>, true},
-    {"caar_np4_kernel<96, 6, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 6 tiles (two workgroups per CU), nt", launch_np4<96, 6, 1, true, 0, 0, false, 6, 2, 0, 0, 43>},
+    {"caar_np4_kernel<96, 6, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 6 tiles (two workgroups per CU), hybrid cache policy", launch_np4<96, 6, 1, 2, 0, 0, false, 6, 2, 0, 0, 32>, true},
+    {"caar_np4_kernel<96, 6, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 6 tiles (two workgroups per CU), nt", launch_np4<96, 6, 1, true, 0, 0, false, 6, 2, 0, 0, 32>},
 };
 int kNp4Nlev96Count = sizeof(kNp4Nlev96) / sizeof(kNp4Nlev96[0]);
 // Any other level count up to 256: the kernel with a run-time level count (NLEV_T = 0).
