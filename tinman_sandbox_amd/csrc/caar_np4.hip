@@ -39,6 +39,9 @@ CAAR_STEPS_DECL(72, 1);
 CAAR_STEPS_DECL(72, 0);
 CAAR_STEPS_DECL(128, 1);
 CAAR_STEPS_DECL(128, 0);
+CAAR_STEPS_DECL(80, 0);
+CAAR_STEPS_DECL(64, 0);
+CAAR_STEPS_DECL(60, 0);
 #undef CAAR_STEPS_DECL
 hipError_t launch_np4_steps_72_auto(const KernelArgs&, int, int, int, hipStream_t);   // cache policy by footprint
 hipError_t launch_np4_steps_128_auto(const KernelArgs&, int, int, int, hipStream_t);
@@ -124,17 +127,17 @@ KernelVariant kNp4Nlev32[] = {
 };
 int kNp4Nlev32Count = sizeof(kNp4Nlev32) / sizeof(kNp4Nlev32[0]);
 KernelVariant kNp4Nlev60[] = {
-    {"caar_np4_kernel<60, 4, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 4, 4, 4, 3 tiles (two workgroups per CU), hybrid cache policy", launch_np4<60, 4, 1, 2, 0, 0, false, 4, 2, 0, 0, 0>, true},
+    {"caar_np4_kernel<60, 4, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 4, 4, 4, 3 tiles (two workgroups per CU), hybrid cache policy", launch_np4<60, 4, 1, 2, 0, 0, false, 4, 2, 0, 0, 0>, true, launch_np4_steps_60_0},
     {"caar_np4_kernel<60, 4, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 4, 4, 4, 3 tiles (two workgroups per CU), nt", launch_np4<60, 4, 1, true, 0, 0, false, 4, 2, 0, 0, 0>},
 };
 int kNp4Nlev60Count = sizeof(kNp4Nlev60) / sizeof(kNp4Nlev60[0]);
 KernelVariant kNp4Nlev64[] = {
-    {"caar_np4_kernel<64, 4, 2, true, 2, 1, false, false, false, 8, 0>", "4 waves x 4 tiles, room for 2 waves/SIMD, hybrid cache policy", launch_np4<64, 4, 2, 2, 1>},
+    {"caar_np4_kernel<64, 4, 2, true, 2, 1, false, false, false, 8, 0>", "4 waves x 4 tiles, room for 2 waves/SIMD, hybrid cache policy", launch_np4<64, 4, 2, 2, 1>, false, launch_np4_steps_64_0},
     {"caar_np4_kernel<64, 4, 2, true, 1, 1, false, false, false, 8, 0>", "4 waves x 4 tiles, room for 2 waves/SIMD, nt", launch_np4<64, 4, 2, true, 1>},
 };
 int kNp4Nlev64Count = sizeof(kNp4Nlev64) / sizeof(kNp4Nlev64[0]);
 KernelVariant kNp4Nlev80[] = {
-    {"caar_np4_kernel<80, 5, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 5 tiles (two workgroups per CU), hybrid cache policy", launch_np4<80, 5, 1, 2, 0, 0, false, 5, 2, 0, 0, 0>, true},
+    {"caar_np4_kernel<80, 5, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 5 tiles (two workgroups per CU), hybrid cache policy", launch_np4<80, 5, 1, 2, 0, 0, false, 5, 2, 0, 0, 0>, true, launch_np4_steps_80_0},
     {"caar_np4_kernel<80, 5, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 5 tiles (two workgroups per CU), nt", launch_np4<80, 5, 1, true, 0, 0, false, 5, 2, 0, 0, 0>},
 };
 int kNp4Nlev80Count = sizeof(kNp4Nlev80) / sizeof(kNp4Nlev80[0]);

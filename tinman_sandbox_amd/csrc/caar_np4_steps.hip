@@ -91,7 +91,7 @@ __global__ __launch_bounds__((WAVES ? WAVES : ((NLEV_T + 3) / 4 + TPW - 1) / TPW
   np4_step_loop<NLEV_T, TPW, MINW, MOIST, POL == 1, POL == 1, PF, PARK, CARRY_LDS, WAVES>(k0, nsteps, rotate, lds);
 }
 
-template <int NLEV, int TPW, int MINW, int POL, int PF, int PARK, int CARRY_LDS = (NLEV <= 72 ? 1 : 0), int WAVES = 0>
+template <int NLEV, int TPW, int MINW, int POL, int PF, int PARK, int CARRY_LDS = (NLEV <= 80 ? 1 : 0), int WAVES = 0>
 static hipError_t launch_np4_steps(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t stream) {
   constexpr int THREADS = (WAVES ? WAVES : ((NLEV + 3) / 4 + TPW - 1) / TPW) * 64;
   if (k.vadv) return hipErrorNotSupported;  // the Eulerian form steps through the graph of single launches
@@ -116,6 +116,12 @@ CAAR_STEPS(72, 5, 2, 1, 0, 0)
 CAAR_STEPS(72, 5, 2, 0, 0, 0)
 CAAR_STEPS(128, 8, 2, 1, 0, 27)
 CAAR_STEPS(128, 8, 2, 0, 0, 27)
+// Other level counts whose carried state fits two workgroups per CU (5 slots x tiles x 512 B + the tile totals <= 80 KB):
+// NLEV=80 (E3SM's 80-level configuration: 4 waves x 5 tiles, 68 KB), 64 (4 x 4), 60 (4, 4, 4, 3).  NLEV=96 (82 KB) and the
+// level counts that are not a multiple of 4 keep the hipGraph of single launches.
+CAAR_STEPS(80, 5, 2, 0, 0, 0)
+CAAR_STEPS(64, 4, 2, 0, 0, 0)
+CAAR_STEPS(60, 4, 2, 0, 0, 0)
 #undef CAAR_STEPS
 // What the default variants use.  From the second call on a call's inputs are the previous call's outputs: n0 state in
 // registers, (NLEV=72) nm1 state and tracer block in LDS, the rest still on chip if the accesses use the DEFAULT cache
