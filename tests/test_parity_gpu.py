@@ -270,7 +270,7 @@ def test_full_size_properties(np_, nlev, E, gold_name):
         assert torch.equal(t, data.arrays[n]), n
 
 
-@pytest.mark.parametrize("np_,nlev,E", [(4, 72, 10000), (4, 128, 12500), (4, 72, 4096), (8, 72, 6000)])
+@pytest.mark.parametrize("np_,nlev,E", [(4, 72, 10000), (4, 128, 12500), (4, 72, 4096), (8, 72, 6000), (4, 80, 9000), (4, 60, 6000), (4, 72, 200)])
 def test_full_size_step_loop_is_bit_identical_to_single_launches(np_, nlev, E):
     """BASELINE sizes through caar_launch_steps: six calls with rotating time levels as ONE launch (the cache policy the
     footprint picks: default policy at 10 000 / 12 500 elements, hybrid at 4 096) against the same six calls launched
