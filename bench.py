@@ -4,6 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1: under a launcher (WORLD_SIZE set) this process is one rank; started plainly with
+--gpus N > 1 it becomes the launcher itself — before anything touches the GPU it starts N fresh rank processes
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), relays rank 0's single JSON line
+and exits with the ranks' exit code (self_launch below).
+
 A "step" is one compute_and_apply_rhs call over every element resident on the GPU
 (fp64, moist branch, the reference's closed-form synthetic arrays).  --gpus 1 is
 BASELINE.json configs[1]: NP=4, NLEV=72, 10 000 elements.  --gpus N > 1 holds 12 500
@@ -46,8 +51,10 @@ def parse():
                     help="total elements of the job, cut into contiguous slabs of ceil(E/N) (overrides "
                          "--elems-per-gpu; the last rank may hold fewer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--isolated", action="store_true",
-                    help="also time 20 launches one by one (roofline.kernel_ms_isolated_*)")
+    ap.add_argument("--isolated", action="store_true", help="(default since round 4; accepted for old command lines)")
+    ap.add_argument("--no-isolated", action="store_true",
+                    help="skip the per-launch timings after the timed region (roofline.kernel_ms_median/_min: max(K, 20) launches "
+                         "back to back with an event after each; kernel_ms_isolated_*: 20 launches one by one)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short extra measurements of BASELINE.json configs[3] and [4]")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -79,39 +86,61 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("CAAR_BENCH_CORES", "16"))))
 
 
-def cpu_baseline(np_, nlev, seconds):
-    """Times the CPU path on the host cores: oracle/_ref (the reference's own C++,
-    kind "reference") when it was built, else oracle/caar_oracle.c (kind "port").
-    Each thread owns a private slab + Control range, the reference's own sharding
-    hook (data_structures.hpp:58-69)."""
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+REF_FLAGS = "g++ -std=c++11 -O3 -fPIC (the reference's own flags, cmake/SetCompilerFlags.cmake:56,123; oracle/Makefile REF_CXXFLAGS)"
+PORT_FLAGS = "gcc -std=c99 -O2 -ffp-contract=off -fPIC (oracle/Makefile ORACLE_CFLAGS)"
+
+
+def cpu_baseline(np_, nlev, seconds, elems=10000):
+    """SURVEY 8(d) / BASELINE.md section 4: the CPU path on the GPU box's host cores, wall clock
+    (time.perf_counter around the C call; the reference's own timer is CLOCK_THREAD_CPUTIME_ID, timer.cpp:37,
+    which would hide stalls).  What is timed: oracle/_ref — the reference's own pointers_only C++ compiled from
+    its sources by oracle/Makefile (kind "reference") — when it was built, else oracle/caar_oracle.c (kind "port").
+      (a) ONE core, the whole `elems`-element data set (configs[1]: 10 000, out of cache), 1 warm-up + 3 timed calls;
+      (b) all host cores, the same `elems` elements cut into one contiguous slab per thread, each thread with its own
+          Control range (the reference's own sharding hook, data_structures.hpp:58-69), `seconds` of wall time each."""
     from oracle import pyoracle as po
     cores = host_cores()
     use_ref = po.have_reference(np_, nlev)
     O = po.Oracle()
-    per_thread = 256
     Dvv = O.dvv_np4(False) if np_ == 4 else O.dvv_gll(np_)
     sc = po.default_scalars(nlev)
 
-    def make_runner():
-        arrs = O.init_arrays(np_, nlev, 1, 3, per_thread)
+    def make_runner(ne):
+        arrs = O.init_arrays(np_, nlev, 1, 3, ne)
         if use_ref:
             R = po.Reference(np_, nlev)
             return lambda: R.compute_and_apply_rhs(arrs, Dvv, sc)
         o = po.Oracle()
         return lambda: o.compute_and_apply_rhs(arrs, Dvv, sc)
 
-    # calibrate repetitions on one thread
-    run = make_runner()
+    # (a) one core, the full data set
+    run = make_runner(elems)
     run()
-    t0 = time.perf_counter()
-    run()
-    dt = time.perf_counter() - t0
-    reps = max(1, int(seconds / max(dt, 1e-6)))
-    single = per_thread / dt
+    one = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run()
+        one.append(time.perf_counter() - t0)
+    del run
+    one_med = sorted(one)[1]
 
-    runners = [make_runner() for _ in range(cores)]
+    # (b) all cores: slabs of the same data set
+    per_thread = -(-elems // cores)
+    reps = max(3, int(round(seconds / (one_med * per_thread / elems))))
+    runners = [make_runner(per_thread) for _ in range(cores)]
     for r in runners:
-        r()  # touch memory
+        r()  # warm-up call (touches the memory)
     barrier = threading.Barrier(cores + 1)
 
     def work(r):
@@ -129,16 +158,27 @@ def cpu_baseline(np_, nlev, seconds):
     wall = time.perf_counter() - t0
     for t in ths:
         t.join()
+    balg = 8 * (21 * np_ * np_ * nlev + 2 * np_ * np_ * (nlev + 1) + 13 * np_ * np_)
+    what = "oracle/_ref (reference cxx/pointers_only)" if use_ref else "oracle/caar_oracle.c"
+    value = cores * per_thread * reps / wall
     return {
-        "value": cores * per_thread * reps / wall,
+        "value": value,
         "unit": "element-updates/s",
         "cores": cores,
         "kind": "reference" if use_ref else "port",
-        "single_core_value": single,
-        "sample": "%d threads x %d elements x %d calls of %s, NP=%d NLEV=%d, wall %.2fs" % (
-            cores, per_thread, reps,
-            "oracle/_ref (reference cxx/pointers_only, g++ -O3)" if use_ref else "oracle/caar_oracle.c (gcc -O2)",
-            np_, nlev, wall),
+        "cpu_model": cpu_model(),
+        "nproc": os.cpu_count(),
+        "nproc_affinity": len(os.sched_getaffinity(0)),
+        "flags": REF_FLAGS if use_ref else PORT_FLAGS,
+        "clock": "wall (time.perf_counter around the calls)",
+        "algorithmic_GBs": value * balg / 1e9,
+        "single_core": {"value": elems / one_med, "elements": elems, "calls": 3, "warmup_calls": 1,
+                        "seconds_per_call": one, "algorithmic_GBs": elems / one_med * balg / 1e9,
+                        "min_seconds": min(one), "median_seconds": one_med},
+        "single_core_value": elems / one_med,
+        "sample": "all cores: %d threads x %d elements (slabs of the %d-element data set) x %d calls of %s, NP=%d NLEV=%d, "
+                  "wall %.2fs; one core: %d elements x 3 calls (median %.3fs)" % (
+                      cores, per_thread, elems, reps, what, np_, nlev, wall, elems, one_med),
     }
 
 
@@ -236,7 +276,10 @@ TRAFFIC_SOURCE_LIVE = ("measured in this run: two child passes of tools/pmc_run.
                        "counters: Infinity-Cache hits are counted as traffic")
 
 
-def live_traffic(np_, nlev, elems, timeout=240):
+STEP_CALLS = 20   # calls per launch of the driver-loop leg (roofline.run_steps) and of its counter pass
+
+
+def live_traffic(np_, nlev, elems, timeout=240, steps=STEP_CALLS):
     """HBM-side bytes per launch of the default kernel, measured NOW: the counters need the profiler around the process,
     so two short child processes run the same launch (same data set size, fresh arrays) under rocprofv3 — one per counter,
     they do not fit one pass — and tools/pmc_parse.py turns them into bytes.  None if rocprofv3 is not there, this process
@@ -255,7 +298,7 @@ def live_traffic(np_, nlev, elems, timeout=240):
             # python3 itself after `--`: no env / shell hop between the profiler and the program
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, ctr), "--",
                    sys.executable, os.path.join(ROOT, "tools", "pmc_run.py"), "--np", str(np_), "--nlev", str(nlev),
-                   "--elems", str(elems)]
+                   "--elems", str(elems), "--steps", str(steps)]
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd="/tmp")
             if r.returncode != 0:
                 return None
@@ -266,7 +309,11 @@ def live_traffic(np_, nlev, elems, timeout=240):
                 "write": j["caar_write_bytes_per_launch"],
                 "calibration": {"FETCH_SIZE_x": j["counters"]["FETCH_SIZE"]["factor_8B_lane"],
                                 "WRITE_SIZE_x": j["counters"]["WRITE_SIZE"]["factor_8B_lane"]},
-                "kernel": j["counters"]["FETCH_SIZE"]["caar_kernel"]}
+                "kernel": j["counters"]["FETCH_SIZE"]["caar_kernel"],
+                "steps": ({"bytes_per_launch": j["steps_hbm_bytes_per_launch"], "read_per_launch": j["steps_read_bytes_per_launch"],
+                           "write_per_launch": j["steps_write_bytes_per_launch"], "calls_per_launch": steps,
+                           "kernel": j["counters"]["FETCH_SIZE"]["steps_kernel"]}
+                          if steps and "steps_hbm_bytes_per_launch" in j else None)}
     except Exception:
         return None
     finally:
@@ -415,11 +462,57 @@ def interleaved_sequences(tsa, torch, args, data, dev, stream, mine, steps):
     return out
 
 
-def run_steps_leg(tsa, torch, args, data, dev, stream, mine, calls=20):
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz = half the guide's FP32 vector peak (157.3); SURVEY 8d
+
+
+def _kernel_key(name):
+    """'void caar::k<1, 2>(args) [clone]' -> 'k<1,2>' (rocprofv3 prints the full signature, the profiles keep the bare name)"""
+    name = name.strip()
+    if name.startswith("void "):
+        name = name[5:]
+    depth, cut = 0, len(name)
+    for i, ch in enumerate(name):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    return name[:cut].replace("caar::", "").replace(" ", "")
+
+
+def issue_profile(kernel_name):
+    """The committed instruction-issue counters of the step-loop kernels (profiles/*/pmc_issue.json, tools/pmc_issue.py:
+    rocprofv3 --pmc SQ_* passes): static, NOT measured in this run.  Newest round first; None if the kernel is not there."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_issue.json")), reverse=True):
+        try:
+            j = json.load(open(path))
+        except Exception:
+            continue
+        for k, row in j.items():
+            if _kernel_key(k) == _kernel_key(kernel_name) and "valu_issue_utilisation" in row:
+                out = {n: row[n] for n in ("valu_issue_utilisation", "mfma_pipe_utilisation", "wave_cycles_waiting_for_any_instruction",
+                                           "lds_bank_conflict_over_lds_active_cycles", "waves_per_simd") if n in row}
+                out["valu_instructions_per_element_call"] = row.get("SQ_INSTS_VALU", {}).get("per_element_call")
+                out["source"] = "static: %s (committed rocprofv3 --pmc SQ_* passes, tools/pmc_issue.py; not measured in this run)" % \
+                    os.path.relpath(path, ROOT)
+                return out
+    return None
+
+
+def run_steps_leg(tsa, torch, args, data, dev, stream, mine, calls=STEP_CALLS):
     """The driver loop itself (main.cpp:113-121 with update_time_levels): `calls` calls with rotating time levels through
     caar_launch_steps — ONE launch where a step-loop kernel exists (every workgroup makes all the calls for its element, the
     prognostic state carried from call to call in registers / LDS; bit-identical to single launches) — against
-    the same calls launched one by one.  Outside the timed region of `value`; the headline is per call and does not use it."""
+    the same calls launched one by one.  Outside the timed region of `value`; the headline is per call and does not use it.
+
+    Its own roofline: the loop does NOT move the algorithmic bytes of `calls` single calls (state that stays on chip is
+    neither re-read nor stored, dead stores are dropped), so dividing those bytes by its time gives a figure above the HBM
+    peak that is no bandwidth.  What is reported instead: the time against the HBM bound of single calls (a time), the
+    fp64 rate against the vector peak (the loop is bound by instruction issue at two waves per SIMD), and — filled in by
+    main() from the live counter pass — the HBM bytes the step-loop kernel really moves per call."""
     lib = tsa.library().lib
     saved = (data.control.n0, data.control.np1, data.control.nm1, data.control.dt2, data.constants.eta_ave_w)
     data.control.dt2, data.constants.eta_ave_w = 1.0e-6, 0.0   # timing only: keeps hundreds of leap-frog steps finite
@@ -442,14 +535,81 @@ def run_steps_leg(tsa, torch, args, data, dev, stream, mine, calls=20):
     finally:
         lib.caar_set_fused_steps(1)
         (data.control.n0, data.control.np1, data.control.nm1, data.control.dt2, data.constants.eta_ave_w) = saved
-    out["speedup"] = out["ms_per_call_single_launches"] / out["ms_per_call_one_launch"]
-    out["element_updates_per_s_one_launch"] = mine / (out["ms_per_call_one_launch"] * 1e-3)
-    out["algorithmic_GBs_one_launch"] = tsa.algorithmic_bytes(args.np_, args.nlev) * mine / (out["ms_per_call_one_launch"] * 1e-3) / 1e9
+    ms = out["ms_per_call_one_launch"]
+    out["speedup"] = out["ms_per_call_single_launches"] / ms
+    out["element_updates_per_s_one_launch"] = mine / (ms * 1e-3)
+    flops = args.nlev * (20 * args.np_ ** 3 + 124 * args.np_ ** 2)        # algorithmic flops per element-update
+    tf = flops * mine / (ms * 1e-3) / 1e12
+    out["roofline"] = {
+        "bound": "valu_issue",
+        "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
+        "flops_per_element_call": flops,
+        "ms_per_call_hbm_bound_of_single_calls": tsa.algorithmic_bytes(args.np_, args.nlev) * mine / (HBM_PEAK_GBS * 1e9) * 1e3,
+        "hbm_bytes_per_call": None, "hbm_GBs": None, "hbm_frac_of_peak": None,   # main(): live counter pass of the step-loop kernel
+        "issue": None,   # main(): the committed SQ-counter profile of the kernel the live pass saw
+        "note": "one launch makes all %d calls per element with the prognostic state on chip: its HBM traffic per call is a fraction "
+                "of a single call's algorithmic bytes (hbm_bytes_per_call, measured), so the single-call HBM bound "
+                "(ms_per_call_hbm_bound_of_single_calls) does not apply to it; results bit-identical to single launches" % calls,
+    }
     return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process starts the N ranks itself and only
+    waits for them.  It imports neither torch nor the library, so nothing here has initialised the GPU (no exec of an
+    initialised process, no fork of one: the ranks are fresh interpreters).  Rank 0 inherits stdout — its ONE JSON line
+    is this command's output —, the other ranks' stdout goes to stderr.  A rank that fails takes the job down: the
+    others (which would wait at a barrier) are terminated by their own PIDs after a short grace, and the exit code is
+    the first non-zero one."""
+    import signal
+    import socket
+    import subprocess
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CAAR_BENCH_LAUNCHER="bench.py")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, failed_at = 0, None
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                c = p.poll()
+                if c is None:
+                    continue
+                live.remove(p)
+                if c != 0 and rc == 0:
+                    rc, failed_at = c, time.monotonic()
+            if failed_at is not None and live and time.monotonic() - failed_at > 15.0:
+                for p in live:
+                    p.terminate()
+                for p in live:
+                    try:
+                        p.wait(10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGINT)
+        rc = 130
+    for p in procs:
+        p.wait()
+    return rc if rc >= 0 else 1
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import tinman_sandbox_amd as tsa
 
@@ -457,8 +617,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs MI355X GPUs (no CPU fallback)")
@@ -477,6 +635,12 @@ def main():
     if world > 1 or os.environ.get("CAAR_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:   # a one-rank group started plainly (CAAR_BENCH_FORCE_DIST=1 python bench.py)
+            import socket
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            s.close()
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -545,21 +709,31 @@ def main():
         lib.caar_select_variant(args.np_, args.nlev, 0)
         (kernel_ms_streaming,) = sharding.max_over_ranks([kernel_ms_streaming], dist, reduce_dev)
 
-    # per-launch spread (median and min), outside the timed region: one event pair per
-    # launch.  These intervals come out ~4 % shorter than the back-to-back average above: a launch
-    # that starts on an idle chip does not share HBM with the write-back of its predecessor's
-    # dirty cache lines.  The headline and roofline.achieved use the back-to-back figure.  Opt-in
-    # (--isolated): these extra launches would otherwise shift the per-kernel average of a
-    # rocprofv3 --stats run of this command away from roofline.kernel_ms.
-    per_launch = []
-    if rank == 0 and args.isolated:
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-        for a, b in evs:
+    # per-launch spread ("median and min"), outside the timed region, two ways:
+    #  * back to back: the K steps once more with an event recorded after every launch; interval i is launch i's time under
+    #    the conditions of the timed region (its predecessor's write-back still draining) -> kernel_ms_median / kernel_ms_min;
+    #  * isolated: one event pair per launch, the stream idle before each (~4 % shorter: a launch that starts on an idle
+    #    chip does not share HBM with its predecessor's dirty lines) -> kernel_ms_isolated_*.
+    # `value` and roofline.achieved use the mean of the timed region above.  --no-isolated skips both (a rocprofv3 --stats
+    # run then sees only spin-up, warm-up and timed launches of this grid; tools/trace_stats.py --window cuts either way).
+    per_launch, back_to_back = [], []
+    if rank == 0 and not args.no_isolated:
+        n = max(args.steps, 20)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        tsa.compute_and_apply_rhs(data, stream)
+        evs[0].record(stream)
+        for i in range(n):
+            tsa.compute_and_apply_rhs(data, stream)
+            evs[i + 1].record(stream)
+        torch.cuda.synchronize(dev)
+        back_to_back = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        for a, b in pairs:
             a.record(stream)
             tsa.compute_and_apply_rhs(data, stream)
             b.record(stream)
-        torch.cuda.synchronize(dev)
-        per_launch = sorted(a.elapsed_time(b) for a, b in evs)
+            torch.cuda.synchronize(dev)
+        per_launch = sorted(a.elapsed_time(b) for a, b in pairs)
 
     if rank == 0:
         balg = tsa.algorithmic_bytes(args.np_, args.nlev)
@@ -584,6 +758,10 @@ def main():
                              "achieved_all_streaming is the all-streaming variant of the same launch shape "
                              "(caar_select_variant 1: every access non-temporal, no cache window)"
                              if args.np_ == 4 and window else "every access streams from/to HBM",
+            "kernel_ms_median": back_to_back[len(back_to_back) // 2] if back_to_back else None,
+            "kernel_ms_min": back_to_back[0] if back_to_back else None,
+            "kernel_ms_max": back_to_back[-1] if back_to_back else None,
+            "frac_median": per_launch_bytes / (back_to_back[len(back_to_back) // 2] * 1e-3) / 1e9 / HBM_PEAK_GBS if back_to_back else None,
             "kernel_ms_isolated_min": per_launch[0] if per_launch else None,
             "kernel_ms_isolated_median": per_launch[len(per_launch) // 2] if per_launch else None,
             # the untimed spin-up before the W warmup steps (see spin_up): how long it took to reach the steady
@@ -631,6 +809,9 @@ def main():
                 "workload": "compute_and_apply_rhs NP=%d NLEV=%d num_elems=%d per GPU (%d total), moist, "
                             "reference closed-form element arrays" % (args.np_, args.nlev, mine, total_elems),
                 "parallelism": "element-sharded x%d, no collectives" % world,
+                "launcher": os.environ.get("CAAR_BENCH_LAUNCHER",
+                                           "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
+                                           ("external" if "WORLD_SIZE" in os.environ else "none")),
                 "kernel": lib.caar_kernel_name(args.np_, args.nlev).decode(),
                 "array_placement": ("caar_arrays_alloc: 64 MiB physical chunks sampled from a temporary pool, every array spread "
                                     "over the device's address classes (DESIGN.md section 5)"
@@ -639,6 +820,15 @@ def main():
             "hbm_gbs_algorithmic_job": total_elems * args.steps * balg / wall_max / 1e9,
             "roofline": roof,
         }
+        if world > 1:
+            # the N=1 line holds another per-GPU size (10 000 = configs[1]); the N=1 figure that is comparable with this
+            # line — same kernel, same elements per GPU — is measured by the N=1 run in a child process:
+            out["config"]["n1_reference"] = {
+                "where": "other_configs[0] of `python bench.py --gpus 1` (element_updates_per_s, kernel_ms, frac_of_hbm_peak)",
+                "workload": "NP=%d NLEV=%d num_elems=%d" % (args.np_, args.nlev, mine),
+                "why": "--gpus 1 is BASELINE configs[1] (10 000 elements); --gpus N>1 holds %d per GPU so that --gpus 8 is "
+                       "configs[2]; efficiency against the headline N=1 value mixes in the size effect" % mine,
+            }
         if world == 1 and not args.no_other_configs and (args.np_, args.nlev) == (4, 72):
             # kernel-only, same run; the headline stays configs[1]:
             #  * 12 500 elements NP=4 NLEV=72 = one GPU's share of configs[2] (what --gpus 8 runs per GPU)
@@ -657,7 +847,16 @@ def main():
                 roof["traffic_over_algorithmic"] = lt["bytes"] / per_launch_bytes
         if world == 1 and not args.no_steps_leg:
             # caar_run_steps / caar_launch_steps: not part of `value`
-            roof["run_steps"] = run_steps_leg(tsa, torch, args, data, dev, stream, mine)
+            roof["run_steps"] = rs = run_steps_leg(tsa, torch, args, data, dev, stream, mine)
+            st = (roof.get("traffic_detail") or {}).get("steps")
+            if st and rs["one_launch_available"]:
+                per_call = st["bytes_per_launch"] / st["calls_per_launch"]
+                gbs = per_call / (rs["ms_per_call_one_launch"] * 1e-3) / 1e9
+                rs["roofline"].update({"hbm_bytes_per_call": per_call, "hbm_GBs": gbs, "hbm_frac_of_peak": gbs / HBM_PEAK_GBS,
+                                       "hbm_bytes_per_element_call": per_call / mine,
+                                       "hbm_bytes_over_single_call_algorithmic": per_call / per_launch_bytes,
+                                       "hbm_kernel": st["kernel"], "hbm_source": TRAFFIC_SOURCE_LIVE,
+                                       "issue": issue_profile(st["kernel"])})
         if world == 1 and not args.no_interleaved:
             seqs = interleaved_sequences(tsa, torch, args, data, dev, stream, mine, args.steps)
             roof["interleaved"] = seqs
@@ -673,8 +872,13 @@ def main():
             del data
             torch.cuda.empty_cache()
             roof["measured_on_this_box"] = measured_ceilings(tsa, torch, dev, args.np_, args.nlev, mine)
+            # against what THIS box's memory system gives a plain copy (best tuned variant), next to the 8 TB/s nominal peak
+            copy = roof["measured_on_this_box"]["stream_copy_GBs"]
+            roof["frac_of_measured_copy"] = roof["achieved"] / copy
+            if "achieved_all_streaming" in roof:
+                roof["frac_of_measured_copy_all_streaming"] = roof["achieved_all_streaming"] / copy
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.np_, args.nlev, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args.np_, args.nlev, args.cpu_seconds, mine)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

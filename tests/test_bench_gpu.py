@@ -56,28 +56,48 @@ def test_single_gpu_line_carries_the_contract_and_the_host_sequences():
     rs = roof["run_steps"]   # the driver loop as one launch, beside the per-call headline
     assert rs["one_launch_available"] and rs["calls_per_launch"] == 20
     assert rs["ms_per_call_one_launch"] > 0 and rs["ms_per_call_single_launches"] > 0
+    # ... with a roofline of its own: an fp64 rate against the vector peak, no "bandwidth" above the HBM peak
+    rr = rs["roofline"]
+    assert rr["bound"] == "valu_issue" and rr["unit"] == "TFLOP/s" and 0 < rr["achieved"] < rr["peak"] == 78.6
+    assert abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-12 and "algorithmic_GBs_one_launch" not in rs
+    # per-launch spread of the single call (median and min), back to back and isolated
+    assert 0 < roof["kernel_ms_min"] <= roof["kernel_ms_median"] <= roof["kernel_ms_max"]
+    assert 0 < roof["kernel_ms_isolated_min"] <= roof["kernel_ms_isolated_median"]
     import shutil
     if shutil.which("rocprofv3"):   # HBM-side traffic from the counters, measured by the run itself
         assert roof["traffic_source"].startswith("measured in this run"), roof["traffic_source"]
         assert 0.995 <= roof["traffic_over_algorithmic"] <= 1.02, roof["traffic_over_algorithmic"]
         assert abs(roof["traffic"] - roof["traffic_detail"]["read"] - roof["traffic_detail"]["write"]) < 1.0
+        # the step-loop kernel's own HBM bytes per call, from the same counter passes: below a single call's, below the peak
+        assert 0 < rr["hbm_bytes_per_call"] < roof["traffic"] and 0 < rr["hbm_frac_of_peak"] < 1.0
+        assert "steps_kernel" in rr["hbm_kernel"]
     cb = j["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
+    # SURVEY 8d / BASELINE.md section 4: CPU model, nproc, flags, and a one-core leg on the whole data set (>= 3 timed calls)
+    assert cb["cpu_model"] and cb["nproc"] >= cb["cores"] and "-O3" in cb["flags"] or cb["kind"] == "port"
+    one = cb["single_core"]
+    assert one["elements"] == 1500 and one["calls"] >= 3 and len(one["seconds_per_call"]) == one["calls"] and one["value"] > 0
 
 
-def test_two_rank_rehearsal_reports_backend_world_size_and_per_gpu_rates():
+@pytest.mark.parametrize("launcher", ["plain", "torch.distributed.run"])
+def test_two_rank_rehearsal_reports_backend_world_size_and_per_gpu_rates(launcher):
+    """`python bench.py --gpus 2` started PLAINLY (bench.py launches its own ranks, self_launch) and under
+    torch.distributed.run (the driver's documented command) give the same line."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = _clean_env()
     env["CAAR_BENCH_BACKEND"] = "gloo"
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "4",
-                        "--warmup", "2", "--elems-per-gpu", "1500", "--no-spinup"], capture_output=True, text=True,
-                       timeout=900, env=env)
+    pre = [sys.executable] if launcher == "plain" else [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+        "--master-port", str(port)]
+    r = subprocess.run(pre + [BENCH, "--gpus", "2", "--steps", "4", "--warmup", "2", "--elems-per-gpu", "1500",
+                              "--no-spinup"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     j = _line(r.stdout)
+    assert j["config"]["launcher"] == ("bench.py" if launcher == "plain" else "torch.distributed.run")
+    assert j["config"]["n1_reference"]["workload"] == "NP=4 NLEV=72 num_elems=1500"
     assert j["n_gpus"] == 2 and j["backend"] == "gloo" and j["dist_world_size"] == 2 and j["scaling"] == "weak"
     assert j["warmup_effective"] == 3
     assert "1500 per GPU (3000 total)" in j["config"]["workload"]
@@ -87,6 +107,26 @@ def test_two_rank_rehearsal_reports_backend_world_size_and_per_gpu_rates():
     assert [p["rank"] for p in per] == [0, 1] and all(p["elements"] == 1500 and p["kernel_ms"] > 0 for p in per)
     assert j["roofline"]["kernel_ms"] == max(p["kernel_ms"] for p in per)
     assert "cpu_baseline" not in j and "interleaved" not in j["roofline"]   # N=1 only
+
+
+def test_a_failing_rank_takes_the_plain_launch_down_with_its_exit_code():
+    """Ranks that reject their configuration (NP=5 has no kernel): the plain launch returns non-zero and prints no JSON line."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--np", "5"], capture_output=True, text=True,
+                       timeout=300, env=dict(_clean_env(), CAAR_BENCH_BACKEND="gloo"))
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_one_rank_under_rccl_started_plainly():
+    """CAAR_BENCH_FORCE_DIST=1 python bench.py --gpus 1: no launcher, no MASTER_PORT in the environment — the one-rank RCCL
+    group rendezvouses on 127.0.0.1 and a port bench.py picks."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "4", "--warmup", "2", "--elems-per-gpu", "1500",
+                        "--no-spinup", "--no-other-configs", "--no-cpu-baseline", "--no-interleaved", "--no-live-traffic",
+                        "--no-steps-leg"], capture_output=True, text=True, timeout=900,
+                       env=dict(_clean_env(), CAAR_BENCH_FORCE_DIST="1"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 1 and j["backend"] == "nccl" and j["dist_world_size"] == 1 and j["config"]["launcher"] == "none"
 
 
 def test_one_rank_under_rccl_takes_the_collective_path():

@@ -87,6 +87,20 @@ def parse(dirs):
             row["lds_bank_conflict_over_lds_active_cycles"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_ACTIVE_INST_LDS")
         if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_INST_ANY") is not None:
             row["wave_cycles_waiting_for_any_instruction"] = g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")
+        # Normalised to the hardware: SQ_BUSY_CYCLES is a per-shader-engine clock count (32 SEs on MI355X: sum / 32 = the
+        # kernel's length in clocks; the r03 passes give 2.35 GHz that way), SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count
+        # quad-cycles (4 clocks: one wave64 VALU instruction occupies its SIMD's issue port for one), SQ_VALU_MFMA_BUSY_CYCLES
+        # clocks of a SIMD's matrix pipe (16 per v_mfma_f64_4x4x4).  1024 SIMDs.
+        NSE, NSIMD = 32, 1024
+        if g("SQ_BUSY_CYCLES"):
+            clocks = g("SQ_BUSY_CYCLES") / NSE
+            row["kernel_clocks"] = clocks
+            if g("SQ_ACTIVE_INST_VALU") is not None:
+                row["valu_issue_utilisation"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / (NSIMD * clocks)
+            if g("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
+                row["mfma_pipe_utilisation"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (NSIMD * clocks)
+            if g("SQ_WAVE_CYCLES") is not None:
+                row["waves_per_simd"] = 4.0 * g("SQ_WAVE_CYCLES") / (NSIMD * clocks)
         res[k.split("(")[0].replace("void caar::", "")] = row
     print(json.dumps(res, indent=1, sort_keys=True))
 

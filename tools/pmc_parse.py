@@ -39,7 +39,8 @@ def main():
         c16 = mean(v for k, v in rows if "stream_copy_kernel<HIP_vector_type<double, 2" in k or
                    ("stream_copy_kernel" in k and "double>" not in k.split("stream_copy_kernel")[1][:10])) * 1024
         skel = mean(v for k, v in rows if "traffic_skeleton" in k) * 1024
-        caar = [(k, v * 1024) for k, v in rows if "caar_np" in k]
+        caar = [(k, v * 1024) for k, v in rows if "caar_np" in k and "steps_kernel" not in k]
+        steps = [(k, v * 1024) for k, v in rows if "caar_np" in k and "steps_kernel" in k]
         out[counter] = {
             "copy8_raw_bytes": c8, "copy16_raw_bytes": c16, "copy_true_bytes": copy_bytes,
             "factor_8B_lane": copy_bytes / c8 if c8 else None,
@@ -48,6 +49,9 @@ def main():
             "caar_raw_bytes": mean(v for _, v in caar),
             "caar_kernel": caar[0][0] if caar else None,
             "caar_launches": len(caar),
+            "steps_raw_bytes": mean(v for _, v in steps) if steps else None,
+            "steps_kernel": steps[0][0] if steps else None,
+            "steps_launches": len(steps),
         }
     f, w = out["FETCH_SIZE"], out["WRITE_SIZE"]
     res = {"counters": out}
@@ -57,6 +61,10 @@ def main():
         res["hbm_bytes_per_launch"] = res["caar_read_bytes_per_launch"] + res["caar_write_bytes_per_launch"]
         res["skeleton_bytes_per_launch"] = f["skeleton_raw_bytes"] * f["factor_8B_lane"] + \
             w["skeleton_raw_bytes"] * w["factor_8B_lane"]
+        if f["steps_raw_bytes"] is not None and w["steps_raw_bytes"] is not None:
+            res["steps_read_bytes_per_launch"] = f["steps_raw_bytes"] * f["factor_8B_lane"]
+            res["steps_write_bytes_per_launch"] = w["steps_raw_bytes"] * w["factor_8B_lane"]
+            res["steps_hbm_bytes_per_launch"] = res["steps_read_bytes_per_launch"] + res["steps_write_bytes_per_launch"]
     print(json.dumps(res, indent=1))
 
 

@@ -22,6 +22,9 @@ ap.add_argument("--np", type=int, default=4, dest="np_")
 ap.add_argument("--nlev", type=int, default=72)
 ap.add_argument("--elems", type=int, default=10000)
 ap.add_argument("--rsplit", type=int, default=1, help="0: the Eulerian form (eta_dot_dpdn, vertical advection)")
+ap.add_argument("--steps", type=int, default=0,
+                help="also 3 launches of the driver loop (caar_launch_steps, this many calls per launch, time levels rotating): "
+                     "the bytes the step-loop kernel really moves (tools/pmc_parse.py: steps_*)")
 a = ap.parse_args()
 L = tsa.library()
 lib = L.lib
@@ -50,5 +53,10 @@ if a.rsplit == 0:
 for _ in range(5):
     tsa.compute_and_apply_rhs(data, st)
 torch.cuda.synchronize()
+if a.steps:
+    data.control.dt2, data.constants.eta_ave_w = 1.0e-6, 0.0   # keeps the leap-frog steps finite (same as bench.py's leg)
+    for _ in range(3):
+        tsa.compute_and_apply_rhs_steps(data, a.steps, True, st)
+    torch.cuda.synchronize()
 print("pmc_run done: copy bytes each way = %d, caar B_alg per launch = %d" % (
     n_copy * 8, tsa.algorithmic_bytes(a.np_, a.nlev) * a.elems))
