@@ -462,6 +462,60 @@ def interleaved_sequences(tsa, torch, args, data, dev, stream, mine, steps):
     return out
 
 
+def subrange_streams_leg(tsa, torch, args, data, dev, stream, mine, nstreams=4, steps=20):
+    """The reference's horizontal-OpenMP pattern on one GPU (data_structures.hpp:58-69: every host thread calls the routine
+    with its own Control{nets, nete}): `nstreams` streams, each stepping its own contiguous quarter of the SAME arrays, side
+    by side.  The hybrid policy's cache window is a budget of the device (element_is_cached keys on the element's index in
+    the arrays), so the four launches together keep one window's worth; round 3 budgeted per launch — emulated here by a
+    window `nstreams` times as large — and all-streaming is the floor.  Time = `steps` rounds of all sub-ranges, main-stream
+    events around the fork/join.  Outside the timed region of `value`."""
+    import copy
+    lib = tsa.library().lib
+    np_, nlev = args.np_, args.nlev
+    side = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    parts = []
+    for i in range(nstreams):
+        d = copy.copy(data)
+        d.control = copy.copy(data.control)
+        d.control.nets, d.control.nete = tsa.shard_range(mine, i, nstreams)
+        parts.append(d)
+    data.dvv_device()
+
+    def rounds(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for s_ in side:
+            s_.wait_stream(stream)
+        for _ in range(n):
+            for d, s_ in zip(parts, side):
+                tsa.compute_and_apply_rhs(d, s_)
+        for s_ in side:
+            stream.wait_stream(s_)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / n
+
+    balg_round = tsa.algorithmic_bytes(np_, nlev) * mine
+    window = int(lib.caar_get_cache_window())
+    out = {"streams": nstreams, "elements_per_stream": [p_.control.nete - p_.control.nets for p_ in parts], "steps": steps}
+    have_twin = np_ == 4 and lib.caar_num_variants(np_, nlev) > 1
+    try:
+        for label, variant, win in (("device_budget", 0, window), ("per_launch_budget_r03", 0, window * nstreams),
+                                    ("all_streaming", 1, window)):
+            if variant and not have_twin:
+                continue
+            lib.caar_select_variant(np_, nlev, variant)
+            lib.caar_set_cache_window(win)
+            rounds(10)
+            ms = min(rounds(steps) for _ in range(3))
+            out[label] = {"ms_per_round": ms, "achieved": balg_round / (ms * 1e-3) / 1e9,
+                          "frac": balg_round / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "cache_window_bytes": win if not variant else 0}
+    finally:
+        lib.caar_select_variant(np_, nlev, 0)
+        lib.caar_set_cache_window(window)
+    return out
+
+
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz = half the guide's FP32 vector peak (157.3); SURVEY 8d
 
 
@@ -866,6 +920,9 @@ def main():
             # ... and with a neighbour that wipes the Infinity Cache between the calls
             roof["achieved_interleaved_evicting"] = seqs["evicting"]["default"]["achieved"]
             roof["frac_interleaved_evicting"] = seqs["evicting"]["default"]["frac"]
+        if world == 1 and not args.no_interleaved and args.np_ == 4:
+            # four host threads / streams on disjoint quarters of the arrays (the reference's horizontal-OpenMP pattern)
+            roof["subrange_streams"] = subrange_streams_leg(tsa, torch, args, data, dev, stream, mine, steps=args.steps)
         if world == 1 and not args.no_other_configs:
             # the same step on [the timed allocation, two more placed allocations, plain torch allocations] (GB/s)
             roof["placement_spread_achieved"] = placement_spread(tsa, torch, args, data, dev, stream, mine, nets)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAAR_ABI_VERSION 4
+#define CAAR_ABI_VERSION 5
 
 enum {
   CAAR_OK = 0,
@@ -141,8 +141,8 @@ int caar_launch(const CaarDims *dims, const CaarArrays *dev, const double *dvv_d
 
 /* `nsteps` consecutive calls (the driver loop main.cpp:113-121), with TestData::update_time_levels
  * (data_structures.cpp:174-180: np1, nm1, n0 <- nm1, n0, np1) between them if rotate != 0, on device-resident arrays:
- * one kernel launch where the selected variant has a step-loop kernel (see caar_set_fused_steps), else nsteps launches
- * of caar_launch (also for rsplit == 0 and for a non-finite eta_ave_w).  Same arguments and rules as caar_launch;
+ * one kernel launch where the selected variant has a step-loop kernel and nsteps >= 2 (see caar_set_fused_steps), else
+ * nsteps launches of caar_launch (also for rsplit == 0 and for a non-finite eta_ave_w).  Same arguments and rules as caar_launch;
  * bit-identical to nsteps calls of it, in every array. */
 int caar_launch_steps(const CaarDims *dims, const CaarArrays *dev, const double *dvv_dev, const CaarParams *params,
                       int nsteps, int rotate, void *stream);
@@ -286,10 +286,16 @@ int caar_set_xcd_chunked(int on);
 /* Hybrid cache policy of the default NP=4 kernels: all element data streams with non-temporal
  * loads and stores, which do not allocate in the 256 MB memory-side Infinity Cache — except the
  * three read-modify-write accumulators (derived_vn0, omega_p, eta_dot_dpdn) of `bytes` worth of
- * elements, spread evenly over every launch, which use the default policy: a host that calls again
+ * elements, which use the default policy: a host that calls again
  * on the same arrays finds them in the cache instead of in HBM (one read and one write saved per
  * byte and call).  Default 224 MiB (best of a sweep: flat from 192 to 240 MiB); 0 makes every access streaming.  Same
- * results either way.  Process-wide, atomic, read once per launch (as the variant selection). */
+ * results either way.  Process-wide, atomic, read once per launch (as the variant selection).
+ * The window is a budget of the DEVICE, not of a launch (ABI 5): which elements are kept is a property of the element's
+ * index in the arrays (an evenly spread subset of dims->num_elems), so launches on sub-ranges [nets, nete) of one array
+ * set — HOMME's horizontal OpenMP threads (data_structures.hpp:58-69), one after the other or side by side on several
+ * streams — together keep what one launch over everything keeps.  Contexts (caar_create) on one device share the window
+ * in proportion to their sizes (caar_context_cache_window: this context's part).  A host that passes several SEPARATE
+ * array sets to the stateless caar_launch on one device divides the budget itself (caar_set_cache_window(total / sets)). */
 #define CAAR_CACHE_WINDOW_DEFAULT (224LL << 20)
 int caar_set_cache_window(long long bytes);
 long long caar_get_cache_window(void);
@@ -377,7 +383,16 @@ typedef struct CaarContext CaarContext;
 int caar_create(CaarContext **ctx, const CaarDims *dims, int device);
 /* The same with the placement of the device arrays chosen by the caller (NULL: as caar_create). */
 int caar_create_ex(CaarContext **ctx, const CaarDims *dims, int device, const CaarPlacement *placement);
+/* Releases the context.  Address-space policy (also caar_arrays_free): a placed arena's virtual address range stays
+ * RESERVED for the life of the process — every chunk is unmapped and its physical memory released (all return codes
+ * checked), but the range is never handed back, because on ROCm 7.2 a range that is reserved again at the same address
+ * has been observed to translate to the chunks it was mapped to before (tools/probes/vmm_va_reuse_probe.hip; treated as
+ * a hypothesis about the driver, the policy is safe either way).  Cost: the arrays' size rounded up to 64 MiB per array
+ * (2 GiB for a 10 000-element NP=4 NLEV=72 set) of the 128 TiB address space per destroyed arena; no memory. */
 void caar_destroy(CaarContext *ctx);
+/* This context's part of the device's cache window (caar_set_cache_window), in bytes: all of it while it is the only
+ * context on its device, else in proportion to the contexts' sizes.  -1 for a NULL context. */
+long long caar_context_cache_window(CaarContext *ctx);
 /* Host -> device copy of all 16 arrays for elements [e0, e1) (element-major layout:
  * one contiguous range per array).  `host` = pointers to element 0 of host arrays
  * holding at least e1 elements. Asynchronous on the context stream. */
@@ -404,15 +419,16 @@ int caar_run(CaarContext *ctx, const CaarParams *params);
  * afterwards, as after nsteps-1 single calls.  The graph is captured on first use and kept while
  * params, nsteps and rotate stay the same.  Asynchronous. */
 int caar_run_steps(CaarContext *ctx, const CaarParams *params, int nsteps, int rotate);
-/* How caar_run_steps issues the calls.  1 (default): as ONE kernel launch where the selected variant has a step-loop
- * kernel (NP=4 NLEV 72 / 128 and NP=8 NLEV 72, rsplit > 0) — elements are independent and every lane only ever touches its own points,
+/* How caar_run_steps / caar_launch_steps issue the calls.  1 (default): as ONE kernel launch where the selected variant
+ * has a step-loop kernel (NP=4 NLEV 72, 128, 80, 64, 60 and NP=8 NLEV 72; rsplit > 0, finite eta_ave_w) and nsteps >= 2 (a
+ * single call is faster through the tuned single launch: hybrid cache window, XCD preference) — elements are independent and every lane only ever touches its own points,
  * so each workgroup makes all nsteps calls for its element back to back: launch fill/drain once per nsteps instead of
  * once per call, the element's arrays still in cache from the second call on; bit-identical to single launches.
  * 0: always a hipGraph of nsteps single launches (what every other configuration uses).  Process-wide, atomic. */
 int caar_set_fused_steps(int on);
 int caar_get_fused_steps(void);
-/* 1 if tuning variant `variant` of (np, nlev) has a step-loop kernel (NP=4 NLEV 72 / 128: the two-workgroup shapes; NP=8: the
- * MFMA forms), else 0. */
+/* 1 if tuning variant `variant` of (np, nlev) has a step-loop kernel (NP=4 NLEV 72 / 128 / 80 / 64 / 60: the
+ * two-workgroup shapes; NP=8 NLEV 72: the MFMA forms), else 0. */
 int caar_has_fused_steps(int np, int nlev, int variant);
 /* Wait for everything enqueued on the context stream. */
 int caar_sync(CaarContext *ctx);

@@ -53,6 +53,11 @@ def test_single_gpu_line_carries_the_contract_and_the_host_sequences():
         assert row["neighbour_ms"] > 0
         for label in ("default", "all_streaming"):
             assert row[label]["sequence_ms"] > row["neighbour_ms"] and row[label]["caar_ms"] > 0
+    sr = roof["subrange_streams"]   # four streams on disjoint quarters of the arrays: ONE cache window per device
+    assert sr["streams"] == 4 and sum(sr["elements_per_stream"]) == 1500
+    for label in ("device_budget", "per_launch_budget_r03", "all_streaming"):
+        assert sr[label]["ms_per_round"] > 0 and 0 < sr[label]["frac"] < 1.2, label
+    assert sr["per_launch_budget_r03"]["cache_window_bytes"] == 4 * sr["device_budget"]["cache_window_bytes"]
     rs = roof["run_steps"]   # the driver loop as one launch, beside the per-call headline
     assert rs["one_launch_available"] and rs["calls_per_launch"] == 20
     assert rs["ms_per_call_one_launch"] > 0 and rs["ms_per_call_single_launches"] > 0

@@ -224,6 +224,34 @@ def test_context_api_roundtrip(oracle):
         L.lib.caar_destroy(ctx)
 
 
+def test_contexts_on_one_device_share_the_cache_window():
+    """The hybrid policy's window is a budget of the device (include/caar.h, ABI 5): one context has all of it, two contexts
+    split it in proportion to their sizes, and a destroyed context gives its part back."""
+    import ctypes as C
+    from tinman_sandbox_amd import caar as m
+    L = tsa.library()
+    lib = L.lib
+    W = lib.caar_get_cache_window()
+    a, b = C.c_void_p(), C.c_void_p()
+    da, db = m._CaarDims(4, 72, 1, 3, 300), m._CaarDims(4, 72, 1, 3, 100)
+    L.check(lib.caar_create(C.byref(a), C.byref(da), 0), "create")
+    try:
+        assert lib.caar_context_cache_window(a) == W
+        L.check(lib.caar_create(C.byref(b), C.byref(db), 0), "create")
+        try:
+            wa, wb = lib.caar_context_cache_window(a), lib.caar_context_cache_window(b)
+            assert abs(wa - 0.75 * W) <= 1 and abs(wb - 0.25 * W) <= 1 and wa + wb <= W
+        finally:
+            lib.caar_destroy(b)
+        assert lib.caar_context_cache_window(a) == W
+        lib.caar_set_cache_window(W // 2)
+        assert lib.caar_context_cache_window(a) == W // 2
+    finally:
+        lib.caar_set_cache_window(W)
+        lib.caar_destroy(a)
+    assert lib.caar_context_cache_window(None) == -1
+
+
 def test_bad_arguments_are_refused():
     arrs, Dvv, sc = cases.make_case("np4_nlev72_closed_dry")
     data = tsa.TestData.from_numpy(arrs, Dvv, sc, device="cuda")

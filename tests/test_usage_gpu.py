@@ -505,10 +505,37 @@ def test_context_api_allocates_through_the_placed_allocator(oracle):
         assert np.array_equal(arrs[n][4:], want[n][4:]), n
 
 
-@pytest.mark.parametrize("np_,nlev,rsplit", [(8, 72, 1), (4, 30, 1), (4, 72, 0), (4, 100, 1)])
-def test_launch_steps_without_a_step_loop_kernel_equals_single_calls(np_, nlev, rsplit):
-    """caar_launch_steps where no fused kernel exists (NP=8, other level counts, the Eulerian form): nsteps launches of
-    caar_launch with the rotation in between — bitwise what the host's own loop gives, Control rotated nsteps times."""
+@pytest.mark.parametrize("np_,nlev,rsplit,knob", [(8, 72, 1, 0), (4, 72, 1, 0), (4, 30, 1, 1), (4, 72, 0, 1), (4, 100, 1, 1)])
+def test_launch_steps_without_a_step_loop_kernel_equals_single_calls(np_, nlev, rsplit, knob):
+    """caar_launch_steps on its host-side fallback — nsteps launches of caar_launch with the rotation in between — where no
+    fused kernel exists (level counts without one, the Eulerian form) and where one exists but is switched off
+    (caar_set_fused_steps(0): NP=8 and NP=4 NLEV=72): bitwise what the host's own loop gives, Control rotated nsteps times."""
+    lib = tsa.library().lib
+    if knob:   # these configurations must not have a step loop of their own for the case to mean what it says
+        assert rsplit == 0 or not any(lib.caar_has_fused_steps(np_, nlev, v) for v in range(lib.caar_num_variants(np_, nlev)))
+    lib.caar_set_fused_steps(knob)
+    try:
+        _steps_fallback_case(np_, nlev, rsplit)
+    finally:
+        lib.caar_set_fused_steps(1)
+
+
+def test_a_single_step_takes_the_tuned_single_launch():
+    """nsteps == 1 never goes to a step-loop kernel (the lone call is what the hybrid-policy single launch is tuned for):
+    same bits either way, and under rocprofv3 the kernel name says which ran; here: the result equals caar_launch's."""
+    arrs = cases.hashed_arrays(4, 72, 6, seed=77)
+    sc = po.default_scalars(72)
+    sc.update(dt2=0.5, qn0=1)
+    a = tsa.TestData.from_numpy(arrs, cases.dvv_for(4), sc, device="cuda")
+    b = tsa.TestData.from_numpy(arrs, cases.dvv_for(4), sc, device="cuda")
+    tsa.compute_and_apply_rhs_steps(a, 1, True)
+    tsa.compute_and_apply_rhs(b)
+    torch.cuda.synchronize()
+    for n in tsa.ARRAY_NAMES:
+        assert torch.equal(a.arrays[n], b.arrays[n]), n
+
+
+def _steps_fallback_case(np_, nlev, rsplit):
     arrs = cases.hashed_arrays(np_, nlev, 5, seed=400 + np_ + nlev)
     Dvv = cases.dvv_for(np_)
     sc = po.default_scalars(nlev)

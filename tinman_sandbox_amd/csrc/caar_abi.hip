@@ -164,6 +164,38 @@ static LaunchChoice launch_choice(const Config* cfg) {
 }
 }  // namespace caar
 
+// The cache window is a budget of the DEVICE: contexts that live on the same device share it in proportion to the bytes
+// the hybrid policy could keep for each (vn0, omega_p, eta_dot_dpdn of every element).  One context gets all of it.
+namespace caar {
+struct DeviceShares {
+  std::mutex mu;
+  long long keepable[64] = {};  // per device: sum over live contexts of num_elems * keepable bytes per element
+};
+static DeviceShares* device_shares() {
+  static DeviceShares* s = new DeviceShares();  // never destroyed (contexts may be released from finalisers at exit)
+  return s;
+}
+static long long keepable_bytes(const CaarDims& d) {
+  const long long pp = (long long)d.np * d.np;
+  return (long long)d.num_elems * 8 * (4 * pp * d.nlev + pp);
+}
+static void device_shares_add(int device, long long bytes) {
+  if (device < 0 || device >= 64) return;
+  DeviceShares* s = device_shares();
+  std::lock_guard<std::mutex> g(s->mu);
+  s->keepable[device] += bytes;
+}
+// this context's part of `window`
+static long long device_share_of(int device, const CaarDims& d, long long window) {
+  if (device < 0 || device >= 64) return window;
+  DeviceShares* s = device_shares();
+  std::lock_guard<std::mutex> g(s->mu);
+  const long long mine = keepable_bytes(d), all = s->keepable[device];
+  if (all <= mine || all <= 0) return window;
+  return (long long)((double)window * ((double)mine / (double)all));
+}
+}  // namespace caar
+
 struct CaarContext {
   CaarDims dims;
   int device;
@@ -180,6 +212,7 @@ struct CaarContext {
   int steps_n, steps_rotate;
   double steps_dvv[64];
   std::vector<double>* steps_hybi;
+  bool shares_registered;  // counted in caar::device_shares()
 };
 
 static double** array_slot(CaarArrays* a, int i) { return reinterpret_cast<double**>(a) + i; }
@@ -359,8 +392,11 @@ static int try_fused_steps(const CaarDims* dims, const CaarArrays* dev, const do
   *rc_out = CAAR_OK;
   // (a non-finite eta_ave_w: the step loops leave out the later calls' `eta_dot_dpdn += eta_ave_w * 0`, which is the
   // identity only where that product is a zero)
-  if (!g_fused_steps.load(std::memory_order_relaxed) || !cfg || !cfg->variants[ch.variant].launch_steps || p->rsplit == 0 ||
-      !(p->eta_ave_w * 0.0 == 0.0))
+  // (nsteps == 1: one call is what the single launch is tuned for — hybrid cache window, XCD preference; the step-loop
+  // kernels run the default or the all-streaming policy and lose 14 % on a lone call, profiles/r03/steps_bench_72_4w_final.log.
+  // From two calls on the loop is ahead: profiles/r04/steps_bench_nsteps.log)
+  if (!g_fused_steps.load(std::memory_order_relaxed) || nsteps < 2 || !cfg || !cfg->variants[ch.variant].launch_steps ||
+      p->rsplit == 0 || !(p->eta_ave_w * 0.0 == 0.0))
     return 0;
   int rc = check_common(dims, p);
   if (rc == CAAR_OK && (!dev || !dvv_dev)) rc = CAAR_EINVAL;
@@ -427,9 +463,14 @@ static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const Caar
     const long long pp = (long long)dims->np * dims->np;
     const long long per_elem = 8 * (4 * pp * dims->nlev + pp);
     const long long n = per_elem > 0 ? ch.cache_window / per_elem : 0;
-    // that many elements, spread evenly over the launch so that in steady state a constant share of the
-    // workgroups is served by the cache instead of HBM
-    k.cache_count = n <= 0 ? 0 : (n >= k.nelem ? k.nelem : (int)n);
+    // that many of the arrays' elements, spread evenly over the WHOLE element range (a property of the element index,
+    // element_is_cached): in steady state a constant share of the workgroups is served by the cache instead of HBM, and
+    // a host that cuts the range into several launches — HOMME's horizontal OpenMP threads on disjoint [nets, nete)
+    // (data_structures.hpp:58-69), one after the other or side by side on several streams — keeps the same set, i.e. ONE
+    // window per device, not one per launch (round 3 budgeted per launch: four sub-range launches claimed 4 x 224 MB of
+    // a 256 MB cache)
+    k.cache_n = dims->num_elems;
+    k.cache_count = n <= 0 ? 0 : (n >= dims->num_elems ? dims->num_elems : (int)n);
   }
   k.n0 = p->n0;
   k.np1 = p->np1;
@@ -783,12 +824,20 @@ int caar_create_ex(CaarContext** out, const CaarDims* dims, int device, const Ca
     caar_destroy(c);
     return e == hipErrorOutOfMemory ? CAAR_ENOMEM : (int)e;
   }
+  caar::device_shares_add(device, caar::keepable_bytes(c->dims));
+  c->shares_registered = true;
   *out = c;
   return CAAR_OK;
 }
 
+long long caar_context_cache_window(CaarContext* c) {
+  if (!c) return -1;
+  return caar::device_share_of(c->device, c->dims, g_cache_window.load(std::memory_order_relaxed));
+}
+
 void caar_destroy(CaarContext* c) {
   if (!c) return;
+  if (c->shares_registered) caar::device_shares_add(c->device, -caar::keepable_bytes(c->dims));
   int caller_dev = -1;  // may run from a finaliser: the calling thread's current device is left as it was
   if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;
   (void)hipSetDevice(c->device);
@@ -898,7 +947,9 @@ int caar_run(CaarContext* c, const CaarParams* p) {
   CaarParams q = *p;
   const double* dvv_dev = nullptr;
   HIP_TRY(c->consts.sync(c->dims, &q, c->stream, &dvv_dev));
-  return caar_launch(&c->dims, &c->dev, dvv_dev, &q, c->stream);
+  caar::LaunchChoice ch = caar::launch_choice(caar::find_config(c->dims.np, c->dims.nlev));
+  ch.cache_window = caar::device_share_of(c->device, c->dims, ch.cache_window);  // the device's window, shared by its contexts
+  return launch_with(&c->dims, &c->dev, dvv_dev, &q, c->stream, &ch);
 }
 
 int caar_run_steps(CaarContext* c, const CaarParams* p, int nsteps, int rotate) {
@@ -914,7 +965,8 @@ int caar_run_steps(CaarContext* c, const CaarParams* p, int nsteps, int rotate) 
   // ... and for the same variant / element mapping / cache window, which fill_args bakes into the
   // captured kernel arguments (a knob changed after the capture must not replay the old launches)
   const caar::Config* cfg = caar::find_config(c->dims.np, c->dims.nlev);
-  const caar::LaunchChoice now = caar::launch_choice(cfg);
+  caar::LaunchChoice now = caar::launch_choice(cfg);
+  now.cache_window = caar::device_share_of(c->device, c->dims, now.cache_window);
   {
     // one launch: every workgroup makes all nsteps calls for its element (caar_np4_steps_kernel)
     int rc = CAAR_OK;

@@ -31,8 +31,10 @@ struct KernelArgs {
   int nets;           // first element of this launch
   int nelem;          // elements in this launch
   int per_xcd;        // 0: element = nets + blockIdx.x; else XCD-chunked mapping (element_of_block)
-  int cache_count;    // hybrid cache policy: that many elements, spread evenly over the launch, keep their
-                      // accumulators in the memory-side cache (0: none)
+  int cache_count;    // hybrid cache policy: that many of the arrays' cache_n elements, spread evenly over the WHOLE
+  int cache_n;        // element range of the arrays (not over the launch), keep their accumulators in the memory-side
+                      // cache (0: none): launches on sub-ranges — one after the other or side by side on several
+                      // streams — together keep exactly the set one launch over everything keeps
   int n0, np1, nm1;
   int qn0;            // -1: dry
   int qsize_d, timelevels;
@@ -65,11 +67,12 @@ __device__ __forceinline__ long long element_of_block(const KernelArgs& k, unsig
   return (s < (unsigned)k.per_xcd && e < k.nelem) ? k.nets + e : -1;
 }
 
-// Hybrid cache policy: is element `rel` (0 .. nelem-1 inside the launch) one of the cache_count evenly
-// spread chosen ones?  (Bresenham: floor((rel+1)*c/n) > floor(rel*c/n).)
-__device__ __forceinline__ bool element_is_cached(const KernelArgs& k, long long rel) {
-  const unsigned long long c = (unsigned)k.cache_count, n = (unsigned)k.nelem;
-  return c != 0 && ((unsigned long long)(rel + 1) * c) / n > ((unsigned long long)rel * c) / n;
+// Hybrid cache policy: is element `ie` (its index in the arrays, 0 .. cache_n-1) one of the cache_count evenly
+// spread chosen ones?  (Bresenham: floor((ie+1)*c/n) > floor(ie*c/n).)  A property of the element, not of the
+// launch that happens to process it: the budget is the device's, however the host cuts the range into launches.
+__device__ __forceinline__ bool element_is_cached(const KernelArgs& k, long long ie) {
+  const unsigned long long c = (unsigned)k.cache_count, n = (unsigned)k.cache_n;
+  return c != 0 && ((unsigned long long)(ie + 1) * c) / n > ((unsigned long long)ie * c) / n;
 }
 
 // 1/x for a normal, non-zero fp64 x: v_rcp_f64 seed + two Newton steps (5 instructions,
@@ -134,13 +137,13 @@ __device__ __forceinline__ KernelArgs reload_args() {
 #define CAAR_F(f) k.f = kp->f;
   CAAR_F(D) CAAR_F(Dinv) CAAR_F(fcor) CAAR_F(spheremp) CAAR_F(metdet) CAAR_F(rmetdet) CAAR_F(dp3d) CAAR_F(v) CAAR_F(T)
   CAAR_F(phis) CAAR_F(Qdp) CAAR_F(eta_dot_dpdn) CAAR_F(omega_p) CAAR_F(phi) CAAR_F(pecnd) CAAR_F(vn0) CAAR_F(Dvv)
-  CAAR_F(hybi) CAAR_F(vadv) CAAR_F(nets) CAAR_F(nelem) CAAR_F(per_xcd) CAAR_F(cache_count) CAAR_F(n0) CAAR_F(np1)
+  CAAR_F(hybi) CAAR_F(vadv) CAAR_F(nets) CAAR_F(nelem) CAAR_F(per_xcd) CAAR_F(cache_count) CAAR_F(cache_n) CAAR_F(n0) CAAR_F(np1)
   CAAR_F(nm1) CAAR_F(qn0) CAAR_F(qsize_d) CAAR_F(timelevels) CAAR_F(nlev) CAAR_F(dt2) CAAR_F(rrearth) CAAR_F(eta_ave_w)
   CAAR_F(rv_over_rd_m1) CAAR_F(Rgas) CAAR_F(kappa) CAAR_F(p_top)
 #undef CAAR_F
   return k;
 }
-static_assert(sizeof(KernelArgs) == 18 * 8 + 12 * 4 + 7 * 8, "reload_args lists every member of KernelArgs");
+static_assert(sizeof(KernelArgs) == 18 * 8 + 13 * 4 + 4 /* padding */ + 7 * 8, "reload_args lists every member of KernelArgs");
 
 // -DCAAR_DEBUG builds (libcaar_hip_debug.so): the reference's only hot-path assertion, check_dp3d
 // (level_vectorized_ppscan/CaarFunctor.hpp:82-97: dp3d(np1) > 0 under !NDEBUG), as a device-side counter instead of an

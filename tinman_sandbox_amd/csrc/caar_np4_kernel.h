@@ -37,8 +37,45 @@ constexpr bool kNp4Mfma = CAAR_NP4_MFMA != 0;
 constexpr int LSTEP = kNp4Mfma ? 4 : 16;
 using Np4Ctx = std::conditional<kNp4Mfma, Mfma4Ctx, RowCoef>::type;
 
+// In the MFMA lane mapping (LSTEP = 4) the scan partners lane -/+ 4, -/+ 8 sit in the lane's own 16-lane row, so the moves
+// are DPP row shifts (row_shr / row_shl: v_mov_b32_dpp, two per fp64 value, no LDS traffic, no lgkmcnt wait) instead of
+// ds_bpermute pairs (CAAR_NP4_SCAN_DPP = 1, default; 0 = the __shfl form of rounds 1-3 for an A/B).  Pure data movement:
+// results are bit-identical to the __shfl form.  A lane without a partner (the row shift runs off the row) must add
+// NOTHING: its addend is -0.0 — x + (-0.0) == x for every x, signed zeros included, which x + 0.0 is not — built from the
+// halves: the low word with bound_ctrl (0 where there is no source lane), the high word keeps `old` = 0x80000000.
+#ifndef CAAR_NP4_SCAN_DPP
+#define CAAR_NP4_SCAN_DPP 1
+#endif
+constexpr bool kScanDpp = kNp4Mfma && CAAR_NP4_SCAN_DPP != 0;
+// Which kernels take the DPP form — measured, two builds alternating on one box (profiles/r04/dppscan_kbench.log,
+// dppscan_steps.log; 405 bit fingerprints of tools/ab_bits.py agree between the builds): NLEV=72 single call 83.6-84.3 ->
+// 86.0-87.3 % of peak (all-streaming 75-75.7 -> 76.4-78.2), step loops 0.1236 -> 0.1049 ms per call at NLEV=72 and
+// 0.2969 -> 0.2535 at NLEV=128 (-15 %: the scans' three dependent ds_bpermute round trips per integral were the longest
+// latency chain of a tile).  The single call at NLEV=128 did not gain (81.2 -> 80.9 %, its all-streaming twin 76.8 -> 75.6):
+// it keeps the __shfl form.
+template <int NLEV_T, bool STEPS>
+constexpr bool np4_scan_dpp() { return kScanDpp && !(NLEV_T == 128 && !STEPS); }
+enum { DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110 };
+// x of the lane CTRL names, or (lanes without a source) -0.0 if NEG_ZERO else +0.0
+template <int CTRL, bool NEG_ZERO>
+__device__ __forceinline__ double dpp_row_shift(double x) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, true);
+  const int hi = NEG_ZERO ? __builtin_amdgcn_update_dpp((int)0x80000000u, (int)(b >> 32), CTRL, 0xf, 0xf, false)
+                          : __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 // inclusive prefix (towards higher levels) and the matching exclusive value
+template <bool DPP>
 __device__ __forceinline__ void scan_down(double x, int lane, int sub, double& incl, double& excl) {
+  if constexpr (DPP) {
+    x += dpp_row_shift<DPP_ROW_SHR + LSTEP, true>(x);      // sub >= 1: + level above
+    x += dpp_row_shift<DPP_ROW_SHR + 2 * LSTEP, true>(x);  // sub >= 2: + the pair above
+    incl = x;
+    excl = dpp_row_shift<DPP_ROW_SHR + LSTEP, false>(x);   // sub == 0: 0.0
+    return;
+  }
   double t = shfl_abs(x, lane - LSTEP);
   if (sub >= 1) x += t;
   t = shfl_abs(x, lane - 2 * LSTEP);
@@ -48,7 +85,15 @@ __device__ __forceinline__ void scan_down(double x, int lane, int sub, double& i
   excl = sub >= 1 ? t : 0.0;
 }
 // inclusive suffix (towards lower level index) and the matching exclusive value
+template <bool DPP>
 __device__ __forceinline__ void scan_up(double x, int lane, int sub, double& incl, double& excl) {
+  if constexpr (DPP) {
+    x += dpp_row_shift<DPP_ROW_SHL + LSTEP, true>(x);      // sub <= 2: + level below
+    x += dpp_row_shift<DPP_ROW_SHL + 2 * LSTEP, true>(x);  // sub <= 1: + the pair below
+    incl = x;
+    excl = dpp_row_shift<DPP_ROW_SHL + LSTEP, false>(x);   // sub == 3: 0.0
+    return;
+  }
   double t = shfl_abs(x, lane + LSTEP);
   if (sub <= 2) x += t;
   t = shfl_abs(x, lane + 2 * LSTEP);
@@ -161,6 +206,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   constexpr bool carry_valid = STEPS && (CARRY_IN & 1);
   constexpr int PP = 16;               // GLL points per level
   constexpr bool DYN = NLEV_T == 0;
+  constexpr bool SCAN_DPP = np4_scan_dpp<NLEV_T, STEPS>();
   constexpr int NT_MAX = DYN ? DYNW * TPW : (NLEV_T + 3) / 4;  // LDS sizing
   const int NLEV = DYN ? k.nlev : NLEV_T;
   // tiles per element incl. dead ones (the last live one partly empty if NLEV % 4 != 0)
@@ -419,8 +465,8 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
       Tv[r] = MOIST ? T[r] * (1.0 + k.rv_over_rd_m1 * (q[r] * recip(dp[r]))) : T[r];               // P:135,150-151
       if (RAGGED && !live_row(r)) Tv[r] = 0.0;  // dead row: dp == 0 made the line above NaN
       double in_dp, in_div;
-      scan_down(dp[r], lane, sub, in_dp, ex_dp[r]);
-      scan_down(divdp[r], lane, sub, in_div, ex_div[r]);
+      scan_down<SCAN_DPP>(dp[r], lane, sub, in_dp, ex_dp[r]);
+      scan_down<SCAN_DPP>(divdp[r], lane, sub, in_div, ex_div[r]);
       if (sub == 3) {
         s_tot_dp[t * PP + pt] = in_dp;
         s_tot_div[t * PP + pt] = in_div;
@@ -454,7 +500,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         double ht = (k.Rgas * Tv[r]) * (dp[r] * rp[r]);          // Rgas*T_v*hkl, hkl = dp/p (P:300-302)
         if (RAGGED && !live_row(r)) ht = 0.0;
         double in_ht;
-        scan_up(ht, lane, sub, in_ht, ex_ht[r]);
+        scan_up<SCAN_DPP>(ht, lane, sub, in_ht, ex_ht[r]);
         if (sub == 0) s_tot_ht[t * PP + pt] = in_ht;
         base_dp += s_tot_dp[t * PP + pt];
         base_div += s_tot_div[t * PP + pt];
@@ -701,7 +747,7 @@ __global__ __launch_bounds__(NLEV_T ? ((NLEV_T + 3) / 4 + TPW - 1) / TPW * 64 : 
     static_assert(!PERSIST, "hybrid cache policy: non-persistent form only");
     const long long ie_s = element_of_block(k, blockIdx.x);
     if (ie_s < 0) return;
-    if (element_is_cached(k, ie_s - k.nets))
+    if (element_is_cached(k, ie_s))
       caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, false, PF, PERSIST, ETA_COND, VADV, DYNW, PARK>(k, lds);
     else
       caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, true, PF, PERSIST, ETA_COND, VADV, DYNW, PARK>(k, lds);

@@ -109,10 +109,21 @@ __device__ __forceinline__ RowCoef make_row_coef(const double* dvv, int lane) {
 //   wa, wb            : the same with the constants taken from Dvv^T.
 __device__ __forceinline__ int mfma4_point(int lane) { return (lane >> 4) * 4 + (lane & 3); }  // a*4 + b
 __device__ __forceinline__ int mfma4_level(int lane) { return (lane >> 2) & 3; }               // level inside the tile
+// CAAR_NP4_DB_DPP = 1 (experiment; default 0): d/db — the contraction over the index that lies inside a lane quad in this
+// mapping — as four quad_perm broadcasts + an FMA chain instead of ds_bpermute + MFMA: no LDS round trip, 11 more VALU
+// instructions per contraction, four more per-lane constants.  Bit-identical to the MFMA form on all 405 fingerprints of
+// tools/ab_bits.py (v_mfma_f64_4x4x4 IS the k-ascending fma chain), and no faster: headline 87.0-87.4 against 87.0-87.5 %,
+// step loop 0.1055 against 0.1048 ms per call (profiles/r04/dbdpp_kbench.log, dbdpp_steps.log).  Not adopted.
+#ifndef CAAR_NP4_DB_DPP
+#define CAAR_NP4_DB_DPP 0
+#endif
 struct Mfma4Ctx {
   double d_hl;  // Dvv[h][l] for lane = 16h + 4blk + l: A operand of da, B operand of db
   double d_lh;  // Dvv[l][h]: A operand of wa, B operand of wb
   int src_t;    // the lane that holds F[l][h] of this lane's level: 16l + 4blk + h
+#if CAAR_NP4_DB_DPP
+  double cb[4];  // Dvv[k][l]
+#endif
 };
 __device__ __forceinline__ Mfma4Ctx make_mfma4_ctx(const double* dvv /* Dvv[k][j] row-major */, int lane) {
   const int h = lane >> 4, blk = (lane >> 2) & 3, l = lane & 3;
@@ -120,13 +131,25 @@ __device__ __forceinline__ Mfma4Ctx make_mfma4_ctx(const double* dvv /* Dvv[k][j
   c.d_hl = dvv[h * 4 + l];
   c.d_lh = dvv[l * 4 + h];
   c.src_t = 16 * l + 4 * blk + h;
+#if CAAR_NP4_DB_DPP
+  for (int k = 0; k < 4; ++k) c.cb[k] = dvv[k * 4 + l];
+#endif
   return c;
 }
 __device__ __forceinline__ double mfma4x4(double a, double b) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, 0.0, 0, 0, 0); }
 // sum_k Dvv[k][a] f[k][b]
 __device__ __forceinline__ double mfma4_d_da(const Mfma4Ctx& c, double f) { return mfma4x4(c.d_hl, f); }
 // sum_k Dvv[k][b] f[a][k]
+#if CAAR_NP4_DB_DPP
+__device__ __forceinline__ double mfma4_d_db(const Mfma4Ctx& c, double f) {
+  double s = c.cb[0] * dpp<0x00>(f);
+  s = __builtin_fma(c.cb[1], dpp<0x55>(f), s);
+  s = __builtin_fma(c.cb[2], dpp<0xAA>(f), s);
+  return __builtin_fma(c.cb[3], dpp<0xFF>(f), s);
+}
+#else
 __device__ __forceinline__ double mfma4_d_db(const Mfma4Ctx& c, double f) { return mfma4x4(__shfl(f, c.src_t, 64), c.d_hl); }
+#endif
 // sum_k Dvv[a][k] f[k][b]
 __device__ __forceinline__ double mfma4_w_a(const Mfma4Ctx& c, double f) { return mfma4x4(c.d_lh, f); }
 // sum_k Dvv[b][k] f[a][k]

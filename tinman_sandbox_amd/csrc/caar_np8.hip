@@ -102,6 +102,10 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pt = MFMA ? mfma_point(lane) : lane;  // GLL point a*8+b of this lane
+  // Slot of this lane's point inside the per-point LDS tables (metric terms, wave totals, T halo): the lane itself — the
+  // MFMA form stages the tables permuted (mfma_lane_of_point), so that every table read of a wave covers 64 consecutive
+  // doubles (indexed by `pt` the reads were 2-way bank conflicts, caar_np8_ops.h load_m22).
+  const int sl = lane;
   const long long ie_s = element_of_block(k, blockIdx.x);
   if (ie_s < 0) return;  // padding block of the XCD-chunked grid (uniform for the workgroup)
   const size_t ie = (size_t)ie_s;
@@ -159,10 +163,13 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
     else if (idx < G_D) src = k.phis + ie * PP + (idx - G_PHIS);
     else if (idx < G_DINV) src = k.D + ie * PP * 4 + (idx - G_D);
     else src = k.Dinv + ie * PP * 4 + (idx - G_DINV);
-    int d = idx;  // D, Dinv: [point][r][c] in memory -> [r*2 + c][point] in LDS (load_m22)
+    // scalars: [point] -> [slot]; D, Dinv: [point][r][c] in memory -> [r*2 + c][slot] in LDS (load_m22)
+    int d;
     if (idx >= G_D) {
       const int base = idx < G_DINV ? G_D : G_DINV, i = idx - base;
-      d = base + (i & 3) * PP + (i >> 2);
+      d = base + (i & 3) * PP + (MFMA ? mfma_lane_of_point(i >> 2) : (i >> 2));
+    } else {
+      d = (idx & ~(PP - 1)) + (MFMA ? mfma_lane_of_point(idx & (PP - 1)) : (idx & (PP - 1)));
     }
     s_geo[d] = stream_load<SNT>(src);
   }
@@ -183,13 +190,13 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
     }
   }
   const double rrearth = k.rrearth;
-  const double rmetdet = s_geo[G_RMETDET + pt];
+  const double rmetdet = s_geo[G_RMETDET + sl];
 
   // ---- phase 1: divdp, T_v; wave totals of dp and divdp -------------------------------
   double divdp[TPW];
   {
-    const M22 Dinv = load_m22(s_geo + G_DINV, pt);
-    const double metdet = s_geo[G_METDET + pt];
+    const M22 Dinv = load_m22(s_geo + G_DINV, sl);
+    const double metdet = s_geo[G_METDET + sl];
     double run_dp = 0.0, run_div = 0.0;
 #pragma unroll
     for (int r = 0; r < TPW; ++r) {
@@ -216,8 +223,8 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
         divdp[r] = divergence_sphere<COEF_LDS>(c, lane, Dinv, metdet, rmetdet, rrearth, x.uv.x * x.dp, x.uv.y * x.dp);  // P:114-121
       }
       if (!RELOAD_T) T[r] = x.T;
-      if (VADV && r == 0) s_Thalo[(w * 2 + 0) * PP + pt] = x.T;
-      if (VADV && r == TPW - 1) s_Thalo[(w * 2 + 1) * PP + pt] = x.T;
+      if (VADV && r == 0) s_Thalo[(w * 2 + 0) * PP + sl] = x.T;
+      if (VADV && r == TPW - 1) s_Thalo[(w * 2 + 1) * PP + sl] = x.T;
       Tv[r] = MOIST ? x.T * (1.0 + k.rv_over_rd_m1 * (x.q * recip(x.dp))) : x.T;  // P:135,150-151
       run_dp += x.dp;
       run_div += divdp[r];
@@ -228,8 +235,8 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    s_tot_dp[w * PP + pt] = run_dp;
-    s_tot_div[w * PP + pt] = run_div;
+    s_tot_dp[w * PP + sl] = run_dp;
+    s_tot_div[w * PP + sl] = run_div;
   }
   wg_sync();
 
@@ -281,12 +288,12 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
   // ---- phase 2: hydrostatic increments, their suffix sums inside the wave ---------------
   double base_dp = 0.0, base_div = 0.0;  // sums over the levels above this wave's first level
   for (int w2 = 0; w2 < w; ++w2) {
-    base_dp += s_tot_dp[w2 * PP + pt];
-    base_div += s_tot_div[w2 * PP + pt];
+    base_dp += s_tot_dp[w2 * PP + sl];
+    base_div += s_tot_div[w2 * PP + sl];
   }
   double sdot_sum = base_div;  // VADV: column total of divdp (X:237)
   if (VADV)
-    for (int w2 = w; w2 < WAVES; ++w2) sdot_sum += s_tot_div[w2 * PP + pt];
+    for (int w2 = w; w2 < WAVES; ++w2) sdot_sum += s_tot_div[w2 * PP + sl];
   double wave_ht;  // sum of the hydrostatic increments over this wave's levels
   {
     double run = base_dp, acc = 0.0;
@@ -299,7 +306,7 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
       __builtin_amdgcn_sched_barrier(0);
     }
     wave_ht = acc;
-    s_tot_ht[w * PP + pt] = acc;
+    s_tot_ht[w * PP + sl] = acc;
   }
 
   double l_eta_last = 0.0;
@@ -308,7 +315,7 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
 
   // ---- phase 3: level-local tendencies and update, top level of the wave first ----------
   double below = 0.0;  // hydrostatic sum over the waves below this one, bottom-up (P:293,302)
-  for (int w2 = WAVES - 1; w2 > w; --w2) below += s_tot_ht[w2 * PP + pt];
+  for (int w2 = WAVES - 1; w2 > w; --w2) below += s_tot_ht[w2 * PP + sl];
 
   double run_dp = base_dp, suml = base_div, run_ht = 0.0;
 #pragma unroll
@@ -326,8 +333,8 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
     // for the whole phase; the pointer is made opaque (but stays an LDS pointer: ds_read, not flat_load, which would
     // queue behind the outstanding global loads) so the loads are not hoisted.
     const lds_cptr geo = lds_reread_ptr(s_geo);
-    const M22 Dinv = load_m22(geo + G_DINV, pt);
-    const double phis = geo[G_PHIS + pt];
+    const M22 Dinv = load_m22(geo + G_DINV, sl);
+    const double phis = geo[G_PHIS + sl];
     const double dpr = park_rd[r * PP], ur = park_rd[BLK + r * PP], vr = park_rd[2 * BLK + r * PP];
     const double Tr = RELOAD_T ? cur.Tn0 : T[RELOAD_T ? 0 : r];
 
@@ -339,7 +346,7 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
     // levels below r inside this wave = wave total - inclusive prefix (P:302's phii)
     const double phi = (phis + (below + (wave_ht - run_ht))) + 0.5 * ht;  // P:303,309
 
-    const M22 Dm = load_m22(geo + G_D, pt);
+    const M22 Dm = load_m22(geo + G_D, sl);
     const double Ephi = 0.5 * dot2(ur, ur, vr, vr) + phi + cur.pec;    // P:196
     double gp0, gp1, gT0, gT1, gE0, gE1, vort;
     if (BATCH) {
@@ -391,8 +398,8 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
       // Neighbouring levels, branch-free: at the top (bottom) level facm (facp) is exactly 0 and
       // the "neighbour" is some other finite value of the park (its last row is a zero pad).
       const int wu = w > 0 ? w - 1 : 0, wd = w < WAVES - 1 ? w + 1 : w;
-      const double T_up = r > 0 ? T[r > 0 ? r - 1 : 0] : s_Thalo[(wu * 2 + 1) * PP + pt];
-      const double T_dn = r < TPW - 1 ? T[r < TPW - 1 ? r + 1 : r] : s_Thalo[(wd * 2 + 0) * PP + pt];
+      const double T_up = r > 0 ? T[r > 0 ? r - 1 : 0] : s_Thalo[(wu * 2 + 1) * PP + sl];
+      const double T_dn = r < TPW - 1 ? T[r < TPW - 1 ? r + 1 : r] : s_Thalo[(wd * 2 + 0) * PP + sl];
       const double u_up = park_rd[BLK + (r - 1) * PP], u_dn = park_rd[BLK + (r + 1) * PP];
       const double v_up = park_rd[2 * BLK + (r - 1) * PP], v_dn = park_rd[2 * BLK + (r + 1) * PP];
       // CaarFunctor.hpp:513-546
@@ -405,7 +412,7 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
     const double gpterm = Tv[r] * rp;                                  // P:219
     const double glnps1 = k.Rgas * gpterm * gp0;                       // P:221
     const double glnps2 = k.Rgas * gpterm * gp1;                       // P:222
-    const double fcor = geo[G_FCOR + pt], spheremp = geo[G_SPHEREMP + pt];
+    const double fcor = geo[G_FCOR + sl], spheremp = geo[G_SPHEREMP + sl];
     double vtens1 = vr * (fcor + vort) - gE0 - glnps1;               // P:227
     double vtens2 = -ur * (fcor + vort) - gE1 - glnps2;              // P:228
     double ttens = -vgrad_T + k.kappa * Tv[r] * om;                    // P:230

@@ -82,6 +82,10 @@ struct M22 {
 // wave read 64 consecutive doubles per component.  Point-major (32-byte stride between lanes) every one of these reads —
 // eight per level and lane in the last phase — was an 8-way bank conflict: SQ_LDS_BANK_CONFLICT 10 900 cycles per
 // element-call against 4 650 LDS-active ones (profiles/r03/pmc_issue.json).
+// `pt`: this lane's slot inside a 64-entry table — the kernels stage every per-point table in the order their lanes hold
+// the points (MFMA form: slot = lane, the table is permuted when it is staged), so the 64 lanes read 64 consecutive doubles.
+// Indexed by the GLL point itself in the MFMA lane mapping (point = 32I + 8h + b for lane = 16h + 8I + b) the two 8-lane
+// groups I = 0, 1 of a 16-lane row lie 32 doubles = 64 banks apart: every read was a 2-way conflict.
 template <class Ptr>  // const double* or lds_cptr
 __device__ __forceinline__ M22 load_m22(Ptr g, int pt) {
   M22 m;
@@ -148,11 +152,30 @@ __device__ __forceinline__ int mfma_point(int lane) {
   const int a = 4 * ((lane >> 3) & 1) + (lane >> 4), b = lane & 7;
   return a * NP + b;
 }
+// ... and its inverse: the lane that holds GLL point p = a*8 + b
+__device__ __forceinline__ int mfma_lane_of_point(int p) {
+  const int a = p >> 3, b = p & 7;
+  return 16 * (a & 3) + 8 * (a >> 2) + b;
+}
+
+// CAAR_NP8_DB_SPREAD = 1 (experiment; default 0): the d/db transpose reads lanes whose ds_bpermute banks (source lane mod
+// 32) are all different.  As the layout stands the 32 lanes of a bpermute group fetch F[4I + l][4K + h] from lane
+// 16l + 8I + 4K + h: rows l and l + 2 collide on every bank (2 extra LDS cycles per ds_bpermute_b32, 2 880 of the 6 468
+// conflict cycles per element-call in profiles/r03/pmc_issue.json).  One DPP row_half_mirror confined to rows 2 and 3
+// (row_mask 0xC: position p of an 8-lane half -> 7 - p, i.e. k-block K <-> 1 - K) first moves their values to the other
+// quad of the half, and src_db points there: conflict-free, pure data movement (bit-identical, tools/ab_bits.py).
+// Measured and NOT adopted: the two extra VALU moves per transpose cost more than the conflict cycles they remove — the
+// NP=8 step loop goes from 1.010 to 1.046 ms per call at 20 000 elements, the single call is unchanged
+// (profiles/r04/np8lds_steps.log, np8lds_kbench.log): these kernels are short of VALU issue slots, not of LDS cycles.
+#ifndef CAAR_NP8_DB_SPREAD
+#define CAAR_NP8_DB_SPREAD 0
+#endif
+constexpr bool kDbSpread = CAAR_NP8_DB_SPREAD != 0;
 
 struct MfmaCtx {
   double a_da[2];  // A operand of d/da for k-block K: Dvv[4K + h][4I + l]     (lane = 16h + 8I + 4J + l)
   double b_db[2];  // B operand of d/db for k-block K: Dvv[4K + h][4J + l]
-  int src_db[2];   // lane that holds F[4I + l][4K + h]: 16l + 8I + 4K + h
+  int src_db[2];   // lane that holds F[4I + l][4K + h]: 16l + 8I + 4K + h (kDbSpread: rows l >= 2 half-mirrored)
 };
 
 __device__ __forceinline__ MfmaCtx make_mfma_ctx(const double* dvv /* Dvv[k][j] row-major, any address space */, int lane) {
@@ -162,7 +185,7 @@ __device__ __forceinline__ MfmaCtx make_mfma_ctx(const double* dvv /* Dvv[k][j] 
   for (int K = 0; K < 2; ++K) {
     c.a_da[K] = dvv[(4 * K + h) * NP + 4 * I + l];
     c.b_db[K] = dvv[(4 * K + h) * NP + 4 * J + l];
-    c.src_db[K] = 16 * l + 8 * I + 4 * K + h;
+    c.src_db[K] = (kDbSpread && l >= 2) ? 16 * l + 8 * I + 7 - (4 * K + h) : 16 * l + 8 * I + 4 * K + h;
   }
   return c;
 }
@@ -186,6 +209,7 @@ __device__ __forceinline__ double mfma_d_da(const MfmaCtx& c, double f) {
 }
 // sum_k Dvv[k][b] f[a][k]
 __device__ __forceinline__ double mfma_d_db(const MfmaCtx& c, double f) {
+  if constexpr (kDbSpread) f = __builtin_amdgcn_update_dpp(f, f, 0x141 /* row_half_mirror */, 0xC /* rows 2, 3 */, 0xf, false);
   const double a0 = __shfl(f, c.src_db[0], 64);
   const double a1 = __shfl(f, c.src_db[1], 64);
   return mfma4(a1, c.b_db[1], mfma4(a0, c.b_db[0], 0.0));
