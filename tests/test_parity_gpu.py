@@ -304,6 +304,8 @@ def test_full_size_step_loop_is_bit_identical_to_single_launches(np_, nlev, E):
     footprint picks: default policy at 10 000 / 12 500 elements, hybrid at 4 096) against the same six calls launched
     one by one — every array bit for bit, and planted copies of one element agree wherever they sit in the grid."""
     lib = tsa.library().lib
+    if not lib.caar_has_fused_steps(np_, nlev, 0):
+        pytest.skip("no step-loop kernel for NLEV=%d in this build (-DCAAR_EXTRA_NLEV=1 holds one)" % nlev)
     a = tsa.TestData().init_data(E, np_, nlev, device="cuda")
     b = tsa.TestData().init_data(E, np_, nlev, device="cuda", place="torch")
     for d in (a, b):
@@ -516,9 +518,15 @@ def test_any_level_count_matches_oracle(oracle, nlev):
     assert lib.caar_supported(4, nlev) and b"<0," in lib.caar_kernel_name(4, nlev)
     arrs = cases.hashed_arrays(4, nlev, 3, seed=200 + nlev)
     Dvv = cases.dvv_for(4)
+    extra_build = lib.caar_num_variants(4, 80) > 1   # -DCAAR_EXTRA_NLEV=1 (caar_kernel_args.h)
     for extra in (dict(), dict(qn0=-1, n0=2, np1=0, nm1=1), dict(rsplit=0), dict(rsplit=0, qn0=-1, nets=1, nete=3)):
         sc = eulerian_scalars(nlev, rsplit=1)
         sc.update(extra)
+        if sc["rsplit"] == 0 and nlev > 128 and not extra_build:
+            # the Eulerian form beyond 128 levels spills registers and is not in the default build: refused, not faked
+            with pytest.raises(tsa.caar.CaarError, match="no kernel compiled"):
+                run_gpu(arrs, Dvv, sc)
+            continue
         want = cases.copy_arrays(arrs)
         oracle.compute_and_apply_rhs(want, Dvv, sc)
         _, got = run_gpu(arrs, Dvv, sc)
@@ -572,6 +580,8 @@ def test_fused_steps_are_bit_identical_to_the_graph_of_single_launches(oracle, n
     from tinman_sandbox_amd import caar as m
     L = tsa.library()
     lib = L.lib
+    if not lib.caar_has_fused_steps(np_, nlev, 0):
+        pytest.skip("no step-loop kernel for NLEV=%d in this build (-DCAAR_EXTRA_NLEV=1 holds one)" % nlev)
     ne = 37 if np_ == 4 else 11
     arrs = cases.hashed_arrays(np_, nlev, ne, seed=77 + nlev + np_)
     # signed zeros in eta_dot_dpdn: the routine adds eta_ave_w * 0 to it in every call, which turns -0 into +0 (or not, for

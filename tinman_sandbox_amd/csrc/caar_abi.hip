@@ -22,9 +22,11 @@ extern KernelVariant kNp4Nlev128[];
 extern int kNp4Nlev128Count;
 extern KernelVariant kNp8Nlev72[];
 extern int kNp8Nlev72Count;
+#if CAAR_EXTRA_NLEV
 extern KernelVariant kNp4Nlev32[], kNp4Nlev60[], kNp4Nlev64[], kNp4Nlev80[], kNp4Nlev96[], kNp4Nlev26[], kNp4Nlev30[];
-extern KernelVariant kNp4NlevAny[];
 extern int kNp4Nlev32Count, kNp4Nlev60Count, kNp4Nlev64Count, kNp4Nlev80Count, kNp4Nlev96Count, kNp4Nlev26Count, kNp4Nlev30Count;
+#endif
+extern KernelVariant kNp4NlevAny[];
 hipError_t launch_state_norms(const double* v, const double* T, const double* dp, int np, int nlev,
                               int timelevels, int tl, int e0, int e1, double* out3_per_elem,
                               hipStream_t stream);
@@ -70,6 +72,7 @@ static Config* configs(int* n) {
       {4, 72, kNp4Nlev72, kNp4Nlev72Count, {0}},
       {4, 128, kNp4Nlev128, kNp4Nlev128Count, {0}},
       {8, 72, kNp8Nlev72, kNp8Nlev72Count, {0}},
+#if CAAR_EXTRA_NLEV
       {4, 32, kNp4Nlev32, kNp4Nlev32Count, {0}},
       {4, 60, kNp4Nlev60, kNp4Nlev60Count, {0}},
       {4, 64, kNp4Nlev64, kNp4Nlev64Count, {0}},
@@ -77,6 +80,7 @@ static Config* configs(int* n) {
       {4, 96, kNp4Nlev96, kNp4Nlev96Count, {0}},
       {4, 26, kNp4Nlev26, kNp4Nlev26Count, {0}},
       {4, 30, kNp4Nlev30, kNp4Nlev30Count, {0}},
+#endif
   };
   *n = (int)(sizeof(c) / sizeof(c[0]));
   return c;
@@ -381,7 +385,8 @@ static int launch_with(const CaarDims* dims, const CaarArrays* dev, const double
   const caar::LaunchChoice ch = forced ? *forced : caar::launch_choice(cfg);  // the knobs, read once
   caar::KernelArgs k;
   fill_args_impl(k, dims, dev, dvv_dev, p, ch);
-  return (int)cfg->variants[ch.variant].launch(k, n, (hipStream_t)stream);
+  const hipError_t e = cfg->variants[ch.variant].launch(k, n, (hipStream_t)stream);
+  return e == hipErrorNotSupported ? CAAR_EUNSUPPORTED : (int)e;  // (a form this build does not hold: rsplit == 0 beyond 128 levels)
 }
 
 // nsteps calls as ONE launch if the chosen variant has a step-loop kernel (and the knob allows it): returns 1 if it was

@@ -4,6 +4,18 @@
 
 #include <hip/hip_runtime.h>
 
+// CAAR_EXTRA_NLEV = 1 (build option, default 0): besides the BASELINE configurations (NP=4 NLEV 72 / 128, NP=8 NLEV 72) and
+// the run-time-level-count kernel that serves every other NLEV in 2..256, also compile
+//   * launch shapes specialised for NLEV 26, 30, 32, 60, 64, 80, 96 (84.7-87 % of peak against 81-87 % through the run-time
+//     count, profiles/r03/anylev_bench.log) and the step loops of NLEV 80 / 64 / 60,
+//   * the Eulerian (rsplit == 0) form of the run-time-level kernel beyond 128 levels (8 waves x 8 tiles: 65-90 spilled VGPRs).
+// None of these is a SURVEY section 8 row; round 3 built them, round 4 took them out of the default library (126 -> 64 NP=4
+// kernel instantiations; every kernel the default build can reach is free of register spills except the Eulerian form at
+// NLEV=128, whose two-workgroup shape spills 14 VGPRs and is still the fastest measured).
+#ifndef CAAR_EXTRA_NLEV
+#define CAAR_EXTRA_NLEV 0
+#endif
+
 namespace caar {
 
 // Device pointers to element 0 of each array (layouts: include/caar.h) plus the

@@ -39,9 +39,11 @@ CAAR_STEPS_DECL(72, 1);
 CAAR_STEPS_DECL(72, 0);
 CAAR_STEPS_DECL(128, 1);
 CAAR_STEPS_DECL(128, 0);
+#if CAAR_EXTRA_NLEV
 CAAR_STEPS_DECL(80, 0);
 CAAR_STEPS_DECL(64, 0);
 CAAR_STEPS_DECL(60, 0);
+#endif
 #undef CAAR_STEPS_DECL
 hipError_t launch_np4_steps_72_auto(const KernelArgs&, int, int, int, hipStream_t);   // cache policy by footprint
 hipError_t launch_np4_steps_128_auto(const KernelArgs&, int, int, int, hipStream_t);
@@ -68,8 +70,10 @@ static int cu_count() {
 // 82.0 against 80.4 % with p / divdp prefix / divdp parked), and NLEV=128 fits its two-workgroup shape at last: 4 waves x 8
 // tiles with ONE scan result (p) parked and u, v, T re-read from the column copy (VPARK = 33: 81.4 KB of LDS, 22 VGPRs
 // spilled) — 77.8 against 72.9 % for 8 waves x 4 tiles, one workgroup per CU (profiles/r03/eulerian_vpark.log).
+// VPOL: the cache policy of the Eulerian form (the NLEV=128 comparator variants all take the hybrid one: one spilling
+// instantiation in the library instead of three).
 template <int NLEV, int TPW, int MINW, int POL, int PF = 0, int PERSIST_WG_PER_CU = 0, bool ETA_COND = false,
-          int VTPW = TPW, int VMINW = MINW, int VPF = PF, int PARK = 0, int VPARK = 0>
+          int VTPW = TPW, int VMINW = MINW, int VPF = PF, int PARK = 0, int VPARK = 0, int VPOL = POL>
 static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = ((NLEV + 3) / 4 + TPW - 1) / TPW * 64;
   constexpr bool PERSIST = PERSIST_WG_PER_CU > 0;
@@ -82,9 +86,9 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
     constexpr int VTHREADS = ((NLEV + 3) / 4 + VTPW - 1) / VTPW * 64;
     if (PERSIST) grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
     if (k.qn0 >= 0)
-      hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, true, POL, VPF, false, false, true, 8, VPARK>), dim3(grid), dim3(VTHREADS), 0, stream, k);
+      hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, true, VPOL, VPF, false, false, true, 8, VPARK>), dim3(grid), dim3(VTHREADS), 0, stream, k);
     else
-      hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, false, POL, VPF, false, false, true, 8, VPARK>), dim3(grid), dim3(VTHREADS), 0, stream, k);
+      hipLaunchKernelGGL((caar_np4_kernel<NLEV, VTPW, VMINW, false, VPOL, VPF, false, false, true, 8, VPARK>), dim3(grid), dim3(VTHREADS), 0, stream, k);
     return hipGetLastError();
   }
   if (k.qn0 >= 0)
@@ -112,15 +116,17 @@ int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
     {"caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS between the phases, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<128, 8, 2, 2, 0, 0, false, 8, 2, 0, 27, 33>, true, launch_np4_steps_128_auto},
-    {"caar_np4_kernel<128, 8, 2, true, 1, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS, nt (all streaming), update loads one tile ahead", launch_np4<128, 8, 2, true, 0, 0, false, 8, 2, 0, 27, 33>, false, launch_np4_steps_128_1},
+    {"caar_np4_kernel<128, 8, 2, true, 1, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS, nt (all streaming), update loads one tile ahead", launch_np4<128, 8, 2, true, 0, 0, false, 8, 2, 0, 27, 33, 2>, false, launch_np4_steps_128_1},
     {"caar_np4_kernel<128, 4, 2, true, 2, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<128, 4, 2, 2, 1, 0, false, 8, 2, 0, 0, 33>},
-    {"caar_np4_kernel<128, 4, 2, true, 1, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 2, 0, 0, 33>},
-    {"caar_np4_kernel<128, 8, 2, true, 0, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), scan results parked in LDS, default cache policy (what a fused multi-step launch wants)", launch_np4<128, 8, 2, 0, 0, 0, false, 8, 2, 0, 27, 33>, true, launch_np4_steps_128_0},
+    {"caar_np4_kernel<128, 4, 2, true, 1, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 2, 0, 0, 33, 2>},
+    {"caar_np4_kernel<128, 8, 2, true, 0, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), scan results parked in LDS, default cache policy (what a fused multi-step launch wants)", launch_np4<128, 8, 2, 0, 0, 0, false, 8, 2, 0, 27, 33, 2>, true, launch_np4_steps_128_0},
 };
 int kNp4Nlev128Count = sizeof(kNp4Nlev128) / sizeof(kNp4Nlev128[0]);
 
 // Other level counts HOMME configurations use (the reference builds any PLEV from config.h):
-// one launch shape each, same kernel template.
+// one launch shape each, same kernel template.  -DCAAR_EXTRA_NLEV=1 builds only (caar_kernel_args.h): by default these level
+// counts run through the run-time-level-count kernel below.
+#if CAAR_EXTRA_NLEV
 KernelVariant kNp4Nlev32[] = {
     {"caar_np4_kernel<32, 2, 1, true, 2, 1, false, false, false, 8, 0>", "4 waves x 2 tiles, room for 1 wave/SIMD, hybrid cache policy", launch_np4<32, 2, 1, 2, 1>},
     {"caar_np4_kernel<32, 2, 1, true, 1, 1, false, false, false, 8, 0>", "4 waves x 2 tiles, room for 1 wave/SIMD, nt", launch_np4<32, 2, 1, true, 1>},
@@ -146,16 +152,22 @@ KernelVariant kNp4Nlev96[] = {
     {"caar_np4_kernel<96, 6, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 6 tiles (two workgroups per CU), nt", launch_np4<96, 6, 1, true, 0, 0, false, 6, 2, 0, 0, 32>},
 };
 int kNp4Nlev96Count = sizeof(kNp4Nlev96) / sizeof(kNp4Nlev96[0]);
+#endif
 // Any other level count up to 256: the kernel with a run-time level count (NLEV_T = 0).
-template <int TPW, int MAXW, int PF, int VPF = 0, int PARK = 0>
+// EUL: whether the Eulerian (rsplit == 0) form is compiled for this shape (it is not where it spills registers)
+template <int TPW, int MAXW, int PF, int VPF = 0, int PARK = 0, bool EUL = true>
 static hipError_t launch_np4_dyn_shape(const KernelArgs& k, int num_elems, hipStream_t stream) {
   const int tiles = (k.nlev + 3) / 4, waves = (tiles + TPW - 1) / TPW;
   const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
   const dim3 block(waves * 64);
   if (waves > MAXW) return hipErrorInvalidValue;
   if (k.vadv) {
-    if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, true, true, VPF, false, false, true, MAXW>), dim3(grid), block, 0, stream, k);
-    else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, false, true, VPF, false, false, true, MAXW>), dim3(grid), block, 0, stream, k);
+    if constexpr (EUL) {
+      if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, true, true, VPF, false, false, true, MAXW>), dim3(grid), block, 0, stream, k);
+      else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, false, true, VPF, false, false, true, MAXW>), dim3(grid), block, 0, stream, k);
+    } else {
+      return hipErrorNotSupported;
+    }
   } else {
     if (k.qn0 >= 0) hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, true, 2, PF, false, false, false, MAXW, PARK>), dim3(grid), block, 0, stream, k);
     else hipLaunchKernelGGL((caar_np4_kernel<0, TPW, 1, false, 2, PF, false, false, false, MAXW, PARK>), dim3(grid), block, 0, stream, k);
@@ -165,23 +177,25 @@ static hipError_t launch_np4_dyn_shape(const KernelArgs& k, int num_elems, hipSt
 static hipError_t launch_np4_dyn(const KernelArgs& k, int num_elems, hipStream_t stream) {
   if (k.nlev < 2 || k.nlev > 256) return hipErrorInvalidValue;
   // FOUR waves where the tiles per wave stay within the registers of this masked form (<= 6 with the MFMA contractions:
-  // 248 VGPRs, the Eulerian form 34 spilled at 6): workgroups of four waves land one wave on every SIMD of a CU, other
+  // 248 VGPRs; the Eulerian form: <= 5, it spills at 6): workgroups of four waves land one wave on every SIMD of a CU, other
   // counts load the SIMDs unevenly (tools/probes/simd_placement_probe.hip)
   const int tiles = (k.nlev + 3) / 4;
   if (tiles <= 8) return launch_np4_dyn_shape<2, 8, 1>(k, num_elems, stream);    // <= 4 waves x 2 tiles
   if (tiles <= 12) return launch_np4_dyn_shape<3, 8, 0>(k, num_elems, stream);   // 4 waves x 3
   if (tiles <= 16) return launch_np4_dyn_shape<4, 8, 0>(k, num_elems, stream);   // 4 waves x 4
   if (tiles <= 20) return launch_np4_dyn_shape<5, 8, 0>(k, num_elems, stream);   // 4 waves x 5
-  if (tiles <= 24) return launch_np4_dyn_shape<6, 8, 0>(k, num_elems, stream);   // 4 waves x 6
-  if (tiles <= 32 && !k.vadv) return launch_np4_dyn_shape<8, 4, 0, 0, 27>(k, num_elems, stream);  // 4 waves x 8 tiles, scan results parked: two workgroups per CU like the NLEV=128 kernel
-  if (tiles <= 32) return launch_np4_dyn_shape<4, 8, 0>(k, num_elems, stream);   // Eulerian form: <= 8 waves x 4 tiles
+  if (tiles <= 32 && k.vadv) return launch_np4_dyn_shape<4, 8, 0>(k, num_elems, stream);   // Eulerian form: <= 8 waves x 4 tiles (no spills)
+  if (tiles <= 24) return launch_np4_dyn_shape<6, 8, 0, 0, 0, false>(k, num_elems, stream);   // 4 waves x 6
+  if (tiles <= 32) return launch_np4_dyn_shape<8, 4, 0, 0, 27, false>(k, num_elems, stream);  // 4 waves x 8 tiles, scan results parked: two workgroups per CU like the NLEV=128 kernel
   // beyond 128 levels: <= 8 waves x 8 tiles, one workgroup per CU, p / divdp prefix / divdp / T_v parked in LDS like the
-  // NLEV=128 kernel (157 KB; 231 VGPRs instead of 52-90 spilled)
-  return launch_np4_dyn_shape<8, 8, 0, 0, 27>(k, num_elems, stream);
+  // NLEV=128 kernel (157 KB; 231 VGPRs).  Its Eulerian form spills 65-90 VGPRs: -DCAAR_EXTRA_NLEV=1 builds only, else the
+  // call fails with hipErrorNotSupported (rsplit == 0 is served up to 128 levels)
+  return launch_np4_dyn_shape<8, 8, 0, 0, 27, CAAR_EXTRA_NLEV != 0>(k, num_elems, stream);
 }
 KernelVariant kNp4NlevAny[] = {{"caar_np4_kernel<0, ...>", "run-time level count (2..256): four waves x 2..6 tiles up to 96 levels, four waves x 8 tiles (scan results parked) up to 128, 8 waves x 8 (parked) beyond, dead rows masked, hybrid cache policy", launch_np4_dyn}};
 
 // level counts that are not a multiple of 4 (last tile partly empty)
+#if CAAR_EXTRA_NLEV
 KernelVariant kNp4Nlev26[] = {
     {"caar_np4_kernel<26, 2, 1, true, 2, 1, false, false, false, 8, 0>", "4 waves x 2, 2, 2, 1 tiles (the last one half empty), hybrid cache policy", launch_np4<26, 2, 1, 2, 1>, true},
     {"caar_np4_kernel<26, 2, 1, true, 1, 1, false, false, false, 8, 0>", "4 waves x 2, 2, 2, 1 tiles, nt", launch_np4<26, 2, 1, true, 1>},
@@ -192,6 +206,7 @@ KernelVariant kNp4Nlev30[] = {
     {"caar_np4_kernel<30, 2, 2, true, 1, 1, false, false, false, 8, 0>", "4 waves x 2 tiles, room for 2 waves/SIMD, nt", launch_np4<30, 2, 2, true, 1>},
 };
 int kNp4Nlev30Count = sizeof(kNp4Nlev30) / sizeof(kNp4Nlev30[0]);
+#endif
 
 #ifdef CAAR_DEBUG
 long long debug_dp3d_count_np4(int reset) { return debug_dp3d_count_of_this_tu(reset); }

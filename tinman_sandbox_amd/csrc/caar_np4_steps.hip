@@ -119,9 +119,11 @@ CAAR_STEPS(128, 8, 2, 0, 0, 27)
 // Other level counts whose carried state fits two workgroups per CU (5 slots x tiles x 512 B + the tile totals <= 80 KB):
 // NLEV=80 (E3SM's 80-level configuration: 4 waves x 5 tiles, 68 KB), 64 (4 x 4), 60 (4, 4, 4, 3).  NLEV=96 (82 KB) and the
 // level counts that are not a multiple of 4 keep the hipGraph of single launches.
+#if CAAR_EXTRA_NLEV
 CAAR_STEPS(80, 5, 2, 0, 0, 0)
 CAAR_STEPS(64, 4, 2, 0, 0, 0)
 CAAR_STEPS(60, 4, 2, 0, 0, 0)
+#endif
 #undef CAAR_STEPS
 // What the default variants use.  From the second call on a call's inputs are the previous call's outputs: n0 state in
 // registers, (NLEV=72) nm1 state and tracer block in LDS, the rest still on chip if the accesses use the DEFAULT cache

@@ -519,11 +519,12 @@ template <int NLEV, int TPW, int MINW, bool NT, bool COEF_LDS = false, bool RELO
 static hipError_t launch_np8(const KernelArgs& k, int num_elems, hipStream_t stream) {
   constexpr int THREADS = NLEV / TPW * 64;
   const int grid = k.per_xcd ? 8 * k.per_xcd : num_elems;
-  if (k.vadv) {  // rsplit == 0: T stays in registers (no RELOAD_T form)
+  if (k.vadv) {  // rsplit == 0: T stays in registers (no RELOAD_T form); every variant takes the MFMA contractions (the
+                 // Eulerian form of the LDS-tile comparators spilled 6 VGPRs, and nothing compares Eulerian forms)
     if (k.qn0 >= 0)
-      hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT, COEF_LDS, false, BATCH, true, MFMA>), dim3(grid), dim3(THREADS), 0, stream, k);
+      hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, true, NT, false, false, false, true, true>), dim3(grid), dim3(THREADS), 0, stream, k);
     else
-      hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false, NT, COEF_LDS, false, BATCH, true, MFMA>), dim3(grid), dim3(THREADS), 0, stream, k);
+      hipLaunchKernelGGL((caar_np8_kernel<NLEV, TPW, MINW, false, NT, false, false, false, true, true>), dim3(grid), dim3(THREADS), 0, stream, k);
     return hipGetLastError();
   }
   if (k.qn0 >= 0)

@@ -72,9 +72,13 @@ def main():
                     for v in range(lib.caar_num_variants(np_, nlev)):
                         lib.caar_select_variant(np_, nlev, v)
                         d = tsa.TestData.from_numpy(cases.copy_arrays(arrs), dvv, sc, device=dev)
-                        for _ in range(3):
-                            tsa.compute_and_apply_rhs(d)
-                            d.update_time_levels()
+                        try:
+                            for _ in range(3):
+                                tsa.compute_and_apply_rhs(d)
+                                d.update_time_levels()
+                        except tsa.caar.CaarError:   # a form this build does not hold (rsplit == 0 beyond 128 levels)
+                            print("np%d nlev%d %s rsplit%d qn0=%d variant %d: refused" % (np_, nlev, kind, rsplit, qn0, v))
+                            continue
                         torch.cuda.synchronize()
                         print("np%d nlev%d %s rsplit%d qn0=%d variant %d single x3: %s" % (np_, nlev, kind, rsplit, qn0, v, digest(d)))
                         if rsplit == 1 and lib.caar_has_fused_steps(np_, nlev, v):
