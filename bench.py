@@ -340,6 +340,16 @@ def spin_up(tsa, torch, data, stream, dev, block=20, max_blocks=40, tol=0.003):
     return blocks
 
 
+def adaptive_state(lib, data):
+    import ctypes as C
+    if not lib.caar_get_adaptive_window():
+        return {"enabled": False}
+    w, st, n = C.c_double(0), C.c_double(0), C.c_longlong(0)
+    state = lib.caar_adaptive_window_state(C.c_void_p(data.arrays["elem_derived_vn0"].data_ptr()), C.byref(w), C.byref(st), C.byref(n))
+    return {"enabled": True, "policy_in_force": {1: "window", 0: "all_streaming", -1: "window (no hybrid kernel / not probed)"}[state],
+            "probe_ms_window": w.value, "probe_ms_all_streaming": st.value, "probes": n.value}
+
+
 def balg_of(tsa, args):
     return tsa.algorithmic_bytes(args.np_, args.nlev)
 
@@ -446,16 +456,24 @@ def interleaved_sequences(tsa, torch, args, data, dev, stream, mine, steps):
                 if variant and not have_twin:
                     continue
                 lib.caar_select_variant(np_, nlev, variant)
+                lib.caar_adaptive_window_reset()   # this leg is a new host pattern: the library starts from its default
                 seq = step_with(other)
-                timed(seq, 10)
+                # the default kernel's adaptive window (include/caar.h) needs its first probe (48 calls) or a drift + probe
+                # (~45 calls) to settle on the policy this pattern wants: the sequence runs untimed until then
+                adapt = 160 if (variant == 0 and lib.caar_get_adaptive_window()) else 10
+                timed(seq, adapt)
                 seq_ms = min(timed(seq, steps) for _ in range(2))
                 caar_ms = seq_ms - other_ms
                 row[label] = {"sequence_ms": seq_ms, "caar_ms": caar_ms, "achieved": balg_launch / (caar_ms * 1e-3) / 1e9,
                               "frac": balg_launch / (caar_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "kernel": lib.caar_kernel_name(np_, nlev).decode()}
+                              "kernel": lib.caar_kernel_name(np_, nlev).decode(), "untimed_calls_before": adapt}
+                if variant == 0:
+                    state = lib.caar_adaptive_window_state(C.c_void_p(data.arrays["elem_derived_vn0"].data_ptr()), None, None, None)
+                    row[label]["policy_in_force"] = {1: "window", 0: "all_streaming (adapted)", -1: "window (not adaptive)"}[state]
             out[name] = row
     finally:
         lib.caar_select_variant(np_, nlev, 0)
+        lib.caar_adaptive_window_reset()
         data.control.n0, data.control.np1, data.control.nm1 = saved
     del vstar, qdp4, qtens, ev_a, ev_b, ev_c
     torch.cuda.empty_cache()
@@ -806,6 +824,9 @@ def main():
             "elements_per_launch": mine,
             "kernel_ms": kernel_ms_max,
             "cache_window_bytes": window if args.np_ == 4 else 0,
+            # the adaptive window (include/caar.h): the policy the library settled on for these arrays during spin-up and
+            # the kernel times of its probe (ms; 7 calls of each policy, medians of the last 4)
+            "cache_window_adaptive": adaptive_state(lib, data),
             "achieved_note": "algorithmic bytes / kernel time with the default hybrid cache policy: the "
                              "accumulators of part of the elements stay in the Infinity Cache between the "
                              "back-to-back calls, so DRAM traffic is lower than the algorithmic bytes; "

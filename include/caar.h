@@ -299,6 +299,23 @@ int caar_set_xcd_chunked(int on);
 #define CAAR_CACHE_WINDOW_DEFAULT (224LL << 20)
 int caar_set_cache_window(long long bytes);
 long long caar_get_cache_window(void);
+/* Adaptive window (default on; ABI 5).  Whether the window pays depends on what the host runs BETWEEN two calls: kept
+ * accumulators are worth +13 % when the next call finds them (the routine replayed, or alternated with kernels that
+ * stream), and -2 % when a neighbour with the default cache policy has evicted them.  The library therefore measures:
+ * per array set (keyed on elem_derived_vn0), whole-range launches of a hybrid-policy kernel are now and then bracketed
+ * by HIP events that are polled, never waited for; after 48 calls, whenever the current policy's kernel time drifts up
+ * by more than 3 %, and every 96 calls while the policy is all-streaming, the other policy runs for 7 calls and the
+ * current one again for 7, and the faster becomes the policy (the window on ties).  Launches inside a stream capture,
+ * on a sub-range, or through caar_run_steps' captured graph use the set's current policy and measure nothing.  Same
+ * results either way (both policies are the same kernel).  caar_set_adaptive_window(0): the window always applies.
+ * caar_adaptive_window_state: the policy in force for the array set whose derived_vn0 is `vn0_dev` (1 window, 0 all
+ * streaming; -1 if the set is unknown) and, where the pointers are not NULL, the medians of the last probe (ms; 0 before
+ * the first) and the number of probes decided so far.  caar_adaptive_window_reset forgets every array set (a host that
+ * changes its call pattern need not call it: drift and re-probes follow; benchmarks that switch patterns use it). */
+int caar_set_adaptive_window(int on);
+int caar_get_adaptive_window(void);
+int caar_adaptive_window_state(const double *vn0_dev, double *ms_window, double *ms_streaming, long long *probes);
+int caar_adaptive_window_reset(void);
 
 /* ---- Fortran-layout ingest / egress -----------------------------------------------
  * A Fortran host holds the same 16 arrays with the FIRST index fastest

@@ -662,3 +662,41 @@ def test_debug_build_counts_nonpositive_layer_thickness(tmp_path):
     env = dict(os.environ, CAAR_LIBRARY="debug")
     r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "DEBUG-BUILD-OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_adaptive_cache_window_changes_the_policy_not_the_results():
+    """include/caar.h "Adaptive window": the library times both cache policies of the default kernel on the host's own call
+    pattern and keeps the faster.  Policies are the same kernel with another cache hint, so results must not move: 130 calls
+    with the adaptive window on (first probe at calls 48-61: seven all-streaming calls in between) equal 130 calls with the
+    window forced, bit for bit; afterwards the library reports a decision that agrees with what it measured."""
+    import ctypes as C
+    lib = tsa.library().lib
+    E = 3000
+    a = tsa.TestData().init_data(E, 4, 72, device="cuda")
+    b = tsa.TestData().init_data(E, 4, 72, device="cuda")
+    for d in (a, b):
+        d.constants.eta_ave_w = 0.01   # (no rotation of the time levels: the np1 state is idempotent, the accumulators grow linearly)
+    assert lib.caar_get_adaptive_window() == 1
+    try:
+        lib.caar_adaptive_window_reset()
+        for _ in range(130):
+            tsa.compute_and_apply_rhs(a)
+        torch.cuda.synchronize()
+        tsa.compute_and_apply_rhs(a)      # (collects the events of the probe)
+        lib.caar_set_adaptive_window(0)
+        for _ in range(131):
+            tsa.compute_and_apply_rhs(b)
+        torch.cuda.synchronize()
+    finally:
+        lib.caar_set_adaptive_window(1)
+    for n in tsa.ARRAY_NAMES:
+        assert torch.equal(a.arrays[n].view(torch.int64), b.arrays[n].view(torch.int64)), n
+        assert torch.isfinite(a.arrays[n]).all(), n
+    w, s, n = C.c_double(0), C.c_double(0), C.c_longlong(0)
+    state = lib.caar_adaptive_window_state(C.c_void_p(a.arrays["elem_derived_vn0"].data_ptr()), C.byref(w), C.byref(s), C.byref(n))
+    assert n.value >= 1 and w.value > 0 and s.value > 0, (state, w.value, s.value, n.value)
+    assert state == (1 if w.value <= s.value * 1.003 else 0)
+    # an array set no whole-range launch was seen of, and the forced-off switch
+    assert lib.caar_adaptive_window_state(C.c_void_p(b.arrays["elem_derived_vn0"].data_ptr()), None, None, None) == -1
+    lib.caar_adaptive_window_reset()
+    assert lib.caar_adaptive_window_state(C.c_void_p(a.arrays["elem_derived_vn0"].data_ptr()), None, None, None) == -1

@@ -100,7 +100,7 @@ class CaarLibrary:
     SYMBOLS = ("caar_supported", "caar_abi_version", "caar_debug_dp3d_violations", "caar_device_count", "caar_strerror", "caar_array_len",
                "caar_algorithmic_bytes", "caar_launch", "caar_launch_steps", "caar_launch_state_norms", "caar_sphere_operator", "caar_sphere_operator_range", "caar_sphere_operator_ex", "caar_euler_step", "caar_preq_hydrostatic", "caar_preq_omega_ps", "caar_sphere_operator_host", "caar_preq_hydrostatic_host", "caar_preq_omega_ps_host", "caar_reciprocal",
                "caar_kernel_name", "caar_num_variants", "caar_select_variant",
-               "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_context_cache_window", "caar_selected_variant", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_stream_copy_tuned", "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_arrays_alloc", "caar_arrays_alloc_ex", "caar_arrays_free", "caar_arrays_placement", "caar_create", "caar_create_ex", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_upload_f90_arrays", "caar_download_f90",
+               "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_context_cache_window", "caar_set_adaptive_window", "caar_get_adaptive_window", "caar_adaptive_window_state", "caar_adaptive_window_reset", "caar_selected_variant", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_stream_copy_tuned", "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_arrays_alloc", "caar_arrays_alloc_ex", "caar_arrays_free", "caar_arrays_placement", "caar_create", "caar_create_ex", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_upload_f90_arrays", "caar_download_f90",
                "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
                "caar_time_runs", "caar_run_steps", "caar_set_fused_steps", "caar_get_fused_steps", "caar_has_fused_steps", "caar_map_host", "caar_run_mapped", "caar_unmap_host")
 
@@ -152,6 +152,7 @@ class CaarLibrary:
         L.caar_set_xcd_chunked.argtypes = [C.c_int]
         L.caar_set_cache_window.argtypes = [C.c_longlong]
         L.caar_get_cache_window.restype = C.c_longlong
+        L.caar_adaptive_window_state.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
         L.caar_context_cache_window.argtypes = [vp]
         L.caar_context_cache_window.restype = C.c_longlong
         L.caar_selected_variant.argtypes = [C.c_int, C.c_int]

@@ -168,6 +168,182 @@ static LaunchChoice launch_choice(const Config* cfg) {
 }
 }  // namespace caar
 
+// ---- adaptive cache window --------------------------------------------------------------------------------------
+// The hybrid policy pays when the accumulators it leaves in the Infinity Cache are still there at the next call: 88 % of
+// the HBM peak (algorithmic) against 77 % all-streaming when the host replays the routine or alternates it with streaming
+// kernels, but 75.9 against 76.7 % when a neighbour with the default cache policy moves a few hundred MB in between and
+// evicts them (profiles/r04/adaptive_window_demo.log; bench.py roofline.interleaved).  What the host runs between two
+// calls cannot be known here, so it is MEASURED: per array set, whole-range launches on a hybrid kernel get a HIP event
+// recorded in front of them now and then (never waited for: polled with hipEventQuery at later calls), and the time from
+// the start of one call to the start of the next is what a call costs the host under the policy it ran with — the kernel
+// AND what it does to the neighbour that follows (under eviction the window-policy kernel itself is the faster one, 0.336
+// against 0.351 ms, and the neighbour pays for writing its dirty lines back: timing the kernel alone picks the wrong side).
+//   * After kFirstProbe calls, whenever the current policy's call-to-call time drifts up by more than kDrift (the host's
+//     pattern changed), and every kReprobe calls while the current policy is all-streaming (trying the window is cheap),
+//     the other policy runs for kWarm + kMeas calls, then the current one again for kWarm + kMeas, and the faster (medians
+//     of the measured calls; the window on ties) becomes the policy.
+//   * A launch inside a stream capture, on a sub-range of the elements, or of a captured graph uses the set's current
+//     policy and measures nothing.
+// Both policies are the same kernel (cache_count == 0 is all-streaming) and give identical results.
+namespace caar {
+struct WindowTuner {
+  static constexpr int kFirstProbe = 48, kWarm = 3, kMeas = 4, kHalf = kWarm + kMeas, kReprobe = 96, kSampleEvery = 8;
+  static constexpr int kProbeEvents = 2 * kHalf + 1;  // one in front of every probe call + one in front of the call after
+  static constexpr double kDrift = 0.03, kTie = 0.003;
+  const void* key = nullptr;  // CaarArrays::elem_derived_vn0 of the set
+  int device = -1;
+  long long calls = 0, since_decision = 0, probes = 0, last_use = 0;
+  int use_window = 1;
+  double ms_window = 0.0, ms_streaming = 0.0;  // medians of the last probe (call-to-call times)
+  double base_ms = 0.0, cur_ms = 0.0;          // the current policy's call-to-call time: at the decision / smoothed since
+  // probe: step 0 = idle; 1 .. 2 kHalf = that call of the probe is next; 2 kHalf + 1 = the closing event is next;
+  // 2 kHalf + 2 = all events recorded, waiting for them to complete
+  int step = 0, probe_first = 0 /* policy of the probe's first half */;
+  hipEvent_t probe_ev[kProbeEvents] = {};
+  hipEvent_t sample_ev[2] = {};
+  int sample = 0;  // 0 idle, 1 = first event recorded at the previous call, 2 = both recorded, waiting
+  bool broken = false;
+
+  void drop_events() {
+    for (auto& x : probe_ev)
+      if (x) (void)hipEventDestroy(x);
+    for (auto& x : sample_ev)
+      if (x) (void)hipEventDestroy(x);
+  }
+  void restart(const void* k, int dev) {
+    drop_events();
+    *this = WindowTuner();
+    key = k;
+    device = dev;
+  }
+};
+struct WindowTuners {
+  std::mutex mu;
+  WindowTuner t[8];
+  long long tick = 0;
+};
+static WindowTuners* window_tuners() {
+  static WindowTuners* w = new WindowTuners();  // never destroyed: no HIP calls from static destructors at exit
+  return w;
+}
+static double median_of(float* v, int n) {
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && v[j] < v[j - 1]; --j) {
+      const float t = v[j];
+      v[j] = v[j - 1];
+      v[j - 1] = t;
+    }
+  return n % 2 ? v[n / 2] : 0.5 * (v[n / 2 - 1] + v[n / 2]);
+}
+}  // namespace caar
+static std::atomic<int> g_adaptive_window{1};
+
+// The policy in force for an array set (1 = window: also for a set no whole-range launch has been seen of)
+static int adaptive_window_current(const CaarArrays* dev, int device) {
+  caar::WindowTuners* all = caar::window_tuners();
+  std::lock_guard<std::mutex> g(all->mu);
+  for (auto& x : all->t)
+    if (x.key == dev->elem_derived_vn0 && x.device == device) return x.use_window;
+  return 1;
+}
+
+// Decides the policy of one whole-range launch on a hybrid kernel and, when the tuner wants a time stamp in front of this
+// call, hands back the event to record there.  Returns 1: use the window, 0: all streaming.
+static int adaptive_window_policy(const CaarArrays* dev, int device, hipStream_t stream, hipEvent_t* before) {
+  using caar::WindowTuner;
+  *before = nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+  caar::WindowTuners* all = caar::window_tuners();
+  std::lock_guard<std::mutex> g(all->mu);
+  WindowTuner* t = nullptr;
+  WindowTuner* lru = &all->t[0];
+  for (auto& x : all->t) {
+    if (x.key == dev->elem_derived_vn0 && x.device == device) t = &x;
+    if (x.last_use < lru->last_use) lru = &x;
+  }
+  if (!t) {
+    if (capturing) return 1;
+    t = lru;
+    t->restart(dev->elem_derived_vn0, device);
+  }
+  t->last_use = ++all->tick;
+  if (capturing) return t->use_window;
+  constexpr int kHalf = WindowTuner::kHalf;
+  auto event = [&](hipEvent_t& e) -> hipEvent_t {
+    if (!e && hipEventCreate(&e) != hipSuccess) {
+      e = nullptr;
+      t->broken = true;
+    }
+    return e;
+  };
+  auto elapsed = [&](hipEvent_t a, hipEvent_t b, float* ms) {
+    *ms = 0.f;
+    return hipEventElapsedTime(ms, a, b) == hipSuccess && *ms > 0.f;
+  };
+  // the passive sample of the current policy: completed?
+  if (t->sample == 2 && hipEventQuery(t->sample_ev[1]) == hipSuccess) {
+    float ms;
+    if (elapsed(t->sample_ev[0], t->sample_ev[1], &ms) && t->step == 0) t->cur_ms = t->cur_ms > 0.0 ? 0.75 * t->cur_ms + 0.25 * ms : ms;
+    t->sample = 0;
+  }
+  // a probe whose events are all recorded: decide once the last one has completed
+  if (t->step == 2 * kHalf + 2 && (t->broken || hipEventQuery(t->probe_ev[2 * kHalf]) == hipSuccess)) {
+    float m[2][WindowTuner::kMeas];
+    bool ok = !t->broken;
+    for (int h = 0; h < 2 && ok; ++h)
+      for (int i = 0; i < WindowTuner::kMeas && ok; ++i) {
+        const int c = h * kHalf + WindowTuner::kWarm + i;  // 0-based probe call: from its start to the next call's start
+        ok = elapsed(t->probe_ev[c], t->probe_ev[c + 1], &m[h][i]);
+      }
+    if (ok) {
+      const double first = caar::median_of(m[0], WindowTuner::kMeas), second = caar::median_of(m[1], WindowTuner::kMeas);
+      t->ms_window = t->probe_first ? first : second;
+      t->ms_streaming = t->probe_first ? second : first;
+      t->use_window = t->ms_window <= t->ms_streaming * (1.0 + WindowTuner::kTie) ? 1 : 0;
+      t->base_ms = t->cur_ms = t->use_window ? t->ms_window : t->ms_streaming;
+      ++t->probes;
+    }
+    t->step = 0;
+    t->broken = false;
+    t->since_decision = 0;
+    t->sample = 0;
+  }
+  (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error code
+  ++t->calls;
+  ++t->since_decision;
+  if (t->step == 0) {
+    const bool first = t->probes == 0 && t->calls == WindowTuner::kFirstProbe;
+    const bool drift = t->probes > 0 && t->base_ms > 0.0 && t->cur_ms > t->base_ms * (1.0 + WindowTuner::kDrift) && t->since_decision > 24;
+    const bool again = t->probes > 0 && !t->use_window && t->since_decision >= WindowTuner::kReprobe;
+    if (first || drift || again) {
+      t->step = 1;
+      t->sample = 0;
+      t->probe_first = t->use_window ? 0 : 1;  // the OTHER policy first, the current one second
+    }
+  }
+  if (t->step >= 1 && t->step <= 2 * kHalf) {
+    const int s = t->step++;  // 1 .. 2 kHalf
+    *before = event(t->probe_ev[s - 1]);
+    return (s - 1) / kHalf == 0 ? t->probe_first : 1 - t->probe_first;
+  }
+  if (t->step == 2 * kHalf + 1) {  // the call after the probe: its start closes the last measured interval
+    *before = event(t->probe_ev[2 * kHalf]);
+    t->step = 2 * kHalf + 2;
+    return t->use_window;
+  }
+  if (t->step == 0) {
+    if (t->sample == 1) {
+      *before = event(t->sample_ev[1]);
+      t->sample = *before ? 2 : 0;
+    } else if (t->sample == 0 && t->calls % WindowTuner::kSampleEvery == 0) {
+      *before = event(t->sample_ev[0]);
+      t->sample = *before ? 1 : 0;
+    }
+  }
+  return t->use_window;
+}
+
 // The cache window is a budget of the DEVICE: contexts that live on the same device share it in proportion to the bytes
 // the hybrid policy could keep for each (vn0, omega_p, eta_dot_dpdn of every element).  One context gets all of it.
 namespace caar {
@@ -287,6 +463,32 @@ int caar_set_cache_window(long long bytes) {
 
 long long caar_get_cache_window(void) { return g_cache_window.load(); }
 
+int caar_set_adaptive_window(int on) {
+  g_adaptive_window.store(on ? 1 : 0);
+  return CAAR_OK;
+}
+int caar_get_adaptive_window(void) { return g_adaptive_window.load(); }
+
+int caar_adaptive_window_state(const double* vn0_dev, double* ms_window, double* ms_streaming, long long* probes) {
+  caar::WindowTuners* all = caar::window_tuners();
+  std::lock_guard<std::mutex> g(all->mu);
+  for (auto& t : all->t)
+    if (t.key && t.key == (const void*)vn0_dev) {
+      if (ms_window) *ms_window = t.ms_window;
+      if (ms_streaming) *ms_streaming = t.ms_streaming;
+      if (probes) *probes = t.probes;
+      return t.use_window;
+    }
+  return -1;
+}
+
+int caar_adaptive_window_reset(void) {
+  caar::WindowTuners* all = caar::window_tuners();
+  std::lock_guard<std::mutex> g(all->mu);
+  for (auto& t : all->t) t.restart(nullptr, -1);
+  return CAAR_OK;
+}
+
 int caar_set_fused_steps(int on) {
   g_fused_steps.store(on ? 1 : 0);
   return CAAR_OK;
@@ -356,7 +558,9 @@ static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const Caar
                            const double* dvv_dev, const CaarParams* p, const caar::LaunchChoice& ch);
 
 static int launch_with(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev, const CaarParams* p,
-                       void* stream, const caar::LaunchChoice* forced);
+                       void* stream, const caar::LaunchChoice* forced, bool tune = true);
+static int adaptive_window_policy(const CaarArrays* dev, int device, hipStream_t stream, hipEvent_t* before);
+static int adaptive_window_current(const CaarArrays* dev, int device);
 
 int caar_launch(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev,
                 const CaarParams* p, void* stream) {
@@ -366,7 +570,7 @@ int caar_launch(const CaarDims* dims, const CaarArrays* dev, const double* dvv_d
 // forced != nullptr: the tuning knobs the caller already read (a graph capture bakes ONE choice into all of
 // its launches and into its cache key)
 static int launch_with(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev, const CaarParams* p,
-                       void* stream, const caar::LaunchChoice* forced) {
+                       void* stream, const caar::LaunchChoice* forced, bool tune) {
   int rc = check_common(dims, p);
   if (rc) return rc;
   if (!dev || !dvv_dev) return CAAR_EINVAL;
@@ -382,9 +586,20 @@ static int launch_with(const CaarDims* dims, const CaarArrays* dev, const double
   const int n = p->nete - p->nets;
   if (n == 0) return CAAR_OK;
 
-  const caar::LaunchChoice ch = forced ? *forced : caar::launch_choice(cfg);  // the knobs, read once
+  caar::LaunchChoice ch = forced ? *forced : caar::launch_choice(cfg);  // the knobs, read once
+  // the adaptive window: whole-range launches of a hybrid kernel with a window to switch off (see adaptive_window_policy)
+  hipEvent_t ev_before = nullptr;
+  if (cfg->variants[ch.variant].hybrid && ch.cache_window > 0 && p->rsplit != 0 && g_adaptive_window.load(std::memory_order_relaxed)) {
+    int device = 0;
+    if (hipGetDevice(&device) == hipSuccess) {
+      const bool measure = tune && n == dims->num_elems;  // else: the set's current policy, nothing measured
+      if (!(measure ? adaptive_window_policy(dev, device, (hipStream_t)stream, &ev_before) : adaptive_window_current(dev, device)))
+        ch.cache_window = 0;
+    }
+  }
   caar::KernelArgs k;
   fill_args_impl(k, dims, dev, dvv_dev, p, ch);
+  if (ev_before) (void)hipEventRecord(ev_before, (hipStream_t)stream);
   const hipError_t e = cfg->variants[ch.variant].launch(k, n, (hipStream_t)stream);
   return e == hipErrorNotSupported ? CAAR_EUNSUPPORTED : (int)e;  // (a form this build does not hold: rsplit == 0 beyond 128 levels)
 }

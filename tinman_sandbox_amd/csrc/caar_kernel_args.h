@@ -190,6 +190,9 @@ struct KernelVariant {
   // nsteps calls (time levels rotating between them if `rotate`) as ONE launch, or nullptr: caar_run_steps then replays a
   // graph of single launches
   hipError_t (*launch_steps)(const KernelArgs&, int num_elems, int nsteps, int rotate, hipStream_t stream) = nullptr;
+  // the kernel runs the hybrid cache policy (POL = 2): KernelArgs::cache_count elements keep their accumulators in the
+  // memory-side cache, 0 makes the same kernel all-streaming — what the adaptive window of caar_abi.hip switches between
+  bool hybrid = false;
 };
 
 // arguments of the stand-alone operator kernels (caar_operators_ex.hip)
