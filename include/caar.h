@@ -402,9 +402,10 @@ int caar_create(CaarContext **ctx, const CaarDims *dims, int device);
 int caar_create_ex(CaarContext **ctx, const CaarDims *dims, int device, const CaarPlacement *placement);
 /* Releases the context.  Address-space policy (also caar_arrays_free): a placed arena's virtual address range stays
  * RESERVED for the life of the process — every chunk is unmapped and its physical memory released (all return codes
- * checked), but the range is never handed back, because on ROCm 7.2 a range that is reserved again at the same address
- * has been observed to translate to the chunks it was mapped to before (tools/probes/vmm_va_reuse_probe.hip; treated as
- * a hypothesis about the driver, the policy is safe either way).  Cost: the arrays' size rounded up to 64 MiB per array
+ * checked), but the range is never handed back, so no address is ever mapped twice.  A conservative policy, not a
+ * demonstrated driver defect: round 2 saw wrong results after an arena had been freed and a new one mapped; the bare-HIP
+ * probe with a control arm (tools/probes/vmm_va_reuse_probe.hip, profiles/r04/vmm_va_reuse_probe.log) reads correct data
+ * through a re-used range in every arm, so the cause is unexplained.  Cost: the arrays' size rounded up to 64 MiB per array
  * (2 GiB for a 10 000-element NP=4 NLEV=72 set) of the 128 TiB address space per destroyed arena; no memory. */
 void caar_destroy(CaarContext *ctx);
 /* This context's part of the device's cache window (caar_set_cache_window), in bytes: all of it while it is the only

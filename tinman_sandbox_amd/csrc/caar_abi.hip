@@ -593,8 +593,11 @@ static int launch_with(const CaarDims* dims, const CaarArrays* dev, const double
     int device = 0;
     if (hipGetDevice(&device) == hipSuccess) {
       const bool measure = tune && n == dims->num_elems;  // else: the set's current policy, nothing measured
-      if (!(measure ? adaptive_window_policy(dev, device, (hipStream_t)stream, &ev_before) : adaptive_window_current(dev, device)))
+      if (!(measure ? adaptive_window_policy(dev, device, (hipStream_t)stream, &ev_before) : adaptive_window_current(dev, device))) {
         ch.cache_window = 0;
+        const int twin = cfg->variants[ch.variant].streaming_twin;  // the all-streaming kernel of the same shape, if there is one
+        if (twin >= 0 && twin < cfg->count) ch.variant = twin;
+      }
     }
   }
   caar::KernelArgs k;

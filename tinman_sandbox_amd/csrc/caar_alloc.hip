@@ -21,12 +21,15 @@
 //
 // Teardown mirrors set-up: every chunk was mapped by its own hipMemMap, so every chunk is unmapped by its own
 // hipMemUnmap, return codes checked, the physical chunks released.  The VIRTUAL range is not given back
-// (hipMemAddressFree): on ROCm 7.2 / gfx950 a range that is freed and later handed out again at the same address still
-// translates to the chunks that were mapped there before — bare-HIP reproducer tools/probes/vmm_va_reuse_probe.hip,
-// profiles/r03/vmm_va_reuse_probe.log: every double written through the re-reserved range misses the chunks mapped
-// there, whether the range was unmapped by one call or chunk by chunk; clean when the second reservation lands
-// elsewhere.  Address space is not scarce (a 10 000-element arena takes 2 GiB of 128 TiB); the physical memory is what
-// is returned.
+// (hipMemAddressFree): a conservative policy, NOT a demonstrated driver defect.  Round 2 saw wrong results after an arena
+// had been freed (with ONE hipMemUnmap over a range mapped chunk by chunk) and a new one mapped; round 3's bare-HIP probe
+// wrote through a re-reserved range and read back through a fresh one and called every double stale — in all of its arms,
+// so the probe itself could not be told from the driver (no control arm).  Round 4's form of the probe
+// (tools/probes/vmm_va_reuse_probe.hip: new chunks filled through a fresh range, mapped into the range under test in a
+// rotated order, READ there; control arm = second mapping at another address) finds every arm clean, same-address re-use
+// included, whether the range was unmapped by one call or chunk by chunk (profiles/r04/vmm_va_reuse_probe.log).  What round
+// 2 saw is therefore unexplained rather than pinned on the driver, and the policy stays because it cannot be wrong:
+// address space is not scarce (a 10 000-element arena takes 2 GiB of 128 TiB); the physical memory is what is returned.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

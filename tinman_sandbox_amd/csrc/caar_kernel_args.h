@@ -193,6 +193,10 @@ struct KernelVariant {
   // the kernel runs the hybrid cache policy (POL = 2): KernelArgs::cache_count elements keep their accumulators in the
   // memory-side cache, 0 makes the same kernel all-streaming — what the adaptive window of caar_abi.hip switches between
   bool hybrid = false;
+  // index (same table) of the all-streaming kernel of the same launch shape, or -1: what the adaptive window launches when
+  // all-streaming is the policy — the twin holds one code path where the hybrid kernel holds two, and is 1.3 % faster than
+  // the hybrid kernel with an empty window (0.3463 against 0.3511 ms, profiles/r04/adaptive_window_demo2.log)
+  int streaming_twin = -1;
 };
 
 // arguments of the stand-alone operator kernels (caar_operators_ex.hip)

@@ -104,7 +104,7 @@ static hipError_t launch_np4(const KernelArgs& k, int num_elems, hipStream_t str
 // (non-const on purpose: const globals are also emitted for the device, where the host
 // launchers they point to do not exist)
 KernelVariant kNp4Nlev72[] = {
-    {"caar_np4_kernel<72, 5, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 5, 5, 4, 4 tiles (two workgroups per CU, one wave of each on every SIMD), hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<72, 5, 1, 2, 0, 0, false, 5, 2, 0, 0, 0>, true, launch_np4_steps_72_auto, true},
+    {"caar_np4_kernel<72, 5, 1, true, 2, 0, false, false, false, 8, 0>", "4 waves x 5, 5, 4, 4 tiles (two workgroups per CU, one wave of each on every SIMD), hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<72, 5, 1, 2, 0, 0, false, 5, 2, 0, 0, 0>, true, launch_np4_steps_72_auto, true, 1},
     {"caar_np4_kernel<72, 5, 1, true, 1, 0, false, false, false, 8, 0>", "4 waves x 5, 5, 4, 4 tiles (two workgroups per CU), nt (all streaming), update loads one tile ahead", launch_np4<72, 5, 1, true, 0, 0, false, 5, 2, 0, 0, 0>, false, launch_np4_steps_72_1},
     {"caar_np4_kernel<72, 6, 1, true, 2, 0, false, false, false, 8, 0>", "3 waves x 6 tiles (two workgroups per CU: 2, 2, 1, 1 waves on the four SIMDs; the default of rounds 2-3), hybrid cache policy, update loads one tile ahead", launch_np4<72, 6, 1, 2, 0, 0, false, 6, 2, 0, 0, 43>, true, nullptr, true},
     {"caar_np4_kernel<72, 2, 1, true, 1, 1, false, false, false, 8, 0>", "9 waves x 2 tiles, nt, update loads before the last barrier", launch_np4<72, 2, 1, true, 1, 0, false, 3, 2, 0>},
@@ -115,7 +115,7 @@ KernelVariant kNp4Nlev72[] = {
 int kNp4Nlev72Count = sizeof(kNp4Nlev72) / sizeof(kNp4Nlev72[0]);
 
 KernelVariant kNp4Nlev128[] = {
-    {"caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS between the phases, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<128, 8, 2, 2, 0, 0, false, 8, 2, 0, 27, 33>, true, launch_np4_steps_128_auto, true},
+    {"caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS between the phases, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads one tile ahead", launch_np4<128, 8, 2, 2, 0, 0, false, 8, 2, 0, 27, 33>, true, launch_np4_steps_128_auto, true, 1},
     {"caar_np4_kernel<128, 8, 2, true, 1, 0, false, false, false, 8, 27>", "4 waves x 8 tiles (two workgroups per CU), p / divdp prefix / divdp / T_v parked in LDS, nt (all streaming), update loads one tile ahead", launch_np4<128, 8, 2, true, 0, 0, false, 8, 2, 0, 27, 33, 2>, false, launch_np4_steps_128_1},
     {"caar_np4_kernel<128, 4, 2, true, 2, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, hybrid cache policy (nt; the accumulators of every n-th element stay in the Infinity Cache), update loads before the last barrier", launch_np4<128, 4, 2, 2, 1, 0, false, 8, 2, 0, 0, 33>, false, nullptr, true},
     {"caar_np4_kernel<128, 4, 2, true, 1, 1, false, false, false, 8, 0>", "8 waves x 4 tiles, nt, update loads before the last barrier", launch_np4<128, 4, 2, true, 1, 0, false, 8, 2, 0, 0, 33, 2>},

@@ -65,7 +65,9 @@ def state():
 timed(caar, 100)
 ev_ms = min(timed(evict, 20) for _ in range(2))
 print("%d elements, %d calls per phase; neighbour alone %.4f ms" % (a.elems, a.calls, ev_ms))
-for mode, adaptive, win in (("adaptive", 1, window), ("window forced", 0, window), ("all-streaming forced", 0, 0)):
+for mode, adaptive, win, variant in (("adaptive", 1, window, 0), ("window forced", 0, window, 0), ("all-streaming forced", 0, 0, 0),
+                                     ("nt twin (variant 1)", 0, 0, 1), ("all-streaming forced", 0, 0, 0), ("nt twin (variant 1)", 0, 0, 1)):
+    lib.caar_select_variant(4, 72, variant)
     lib.caar_set_adaptive_window(adaptive)
     lib.caar_set_cache_window(win)
     lib.caar_adaptive_window_reset()
@@ -75,5 +77,6 @@ for mode, adaptive, win in (("adaptive", 1, window), ("window forced", 0, window
         #                                                                 now and then hit by a driver stall of tens of ms)
         print("%-22s %-22s CAAR %.4f ms per call over the phase (%.1f %% of peak), %.4f settled (%.1f %%)%s" % (
             mode, phase, whole, balg / whole / 8e7, tail, balg / tail / 8e7, "   policy: " + state() if adaptive else ""), flush=True)
+lib.caar_select_variant(4, 72, 0)
 lib.caar_set_adaptive_window(1)
 lib.caar_set_cache_window(window)
