@@ -55,6 +55,13 @@ def check_outputs(got, want, sc, tag, pure_elementwise=None):
         assert err <= RTOL, (tag, n, "field-relative", err)
         bad = np.abs(g - w) > RTOL * np.abs(w) + 1e-14 * scale
         assert not bad.any(), (tag, n, "elementwise", int(bad.sum()))
+        # ... and WITHOUT the absolute term wherever the entry is not a near-cancellation (>= 1 % of the field's magnitude):
+        # north_star's 1e-12 relative, element by element (the absolute term above only ever serves entries that cancel to
+        # ~0 in the amplified stress cases; measured errors are <= 1.3e-15 of the field's magnitude)
+        big = np.abs(w) >= 1e-2 * scale
+        if big.any():
+            rel = np.abs(g - w)[big] / np.abs(w)[big]
+            assert rel.max() <= RTOL, (tag, n, "elementwise relative on entries >= 1 % of the field", float(rel.max()))
         if pure_elementwise is not None:
             assert cases.rel_err(g, w) <= pure_elementwise, (tag, n, cases.rel_err(g, w))
     return worst

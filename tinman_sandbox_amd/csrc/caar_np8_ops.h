@@ -201,10 +201,24 @@ __device__ __forceinline__ double mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+// CAAR_NP8_DA_SELECT = 1 (default since round 4): the two B operands of d/da from ONE unmasked row_ror:8 (the value 8 lanes
+// away in the row, for every lane: two v_mov_b32_dpp into a fresh register) and two selects by the lane's half of the row
+// (v_cndmask with a constant lane mask) — 6 VALU instructions.  0: two bank-masked DPP moves (rounds 2-3), each of which
+// first copies the field (the masked lanes keep `old`): 8.  Pure data movement, bit-identical.
+#ifndef CAAR_NP8_DA_SELECT
+#define CAAR_NP8_DA_SELECT 1
+#endif
 // sum_k Dvv[k][a] f[k][b] at this lane's point (a, b)
 __device__ __forceinline__ double mfma_d_da(const MfmaCtx& c, double f) {
+#if CAAR_NP8_DA_SELECT
+  const double p = __builtin_amdgcn_update_dpp(0.0, f, 0x128, 0xf, 0xf, true);  // row_ror:8, every lane has a source
+  const bool upper = (__lane_id() & 8) != 0;                                    // I = 1: lanes 8..15 of each row
+  const double b0 = upper ? p : f;  // block row K = 0: lanes 8..15 take lane - 8's value
+  const double b1 = upper ? f : p;  // block row K = 1: lanes 0..7 take lane + 8's value
+#else
   const double b0 = swap8_banked<0xC>(f);  // block row K = 0: lanes 8..15 of each row take lane - 8's value
   const double b1 = swap8_banked<0x3>(f);  // block row K = 1: lanes 0..7 take lane + 8's value
+#endif
   return mfma4(c.a_da[1], b1, mfma4(c.a_da[0], b0, 0.0));
 }
 // sum_k Dvv[k][b] f[a][k]
