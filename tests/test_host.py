@@ -167,3 +167,31 @@ int main(void) {
                     "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     assert "caar_np4_kernel<72" in out and "no kernel" in out
+
+
+def test_shipped_code_object_holds_what_design_says():
+    """DESIGN.md section 7 (round 4): the default library holds the BASELINE configurations and the run-time-level kernel —
+    fewer than 100 CAAR kernel instantiations — and every kernel is free of register spills except the documented one
+    (the Eulerian NLEV=128 default).  Read from the library itself (tools/codeobj_stats.py: AMDGPU metadata notes)."""
+    import importlib.util
+    import shutil
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf") or shutil.which("c++filt") is None:
+        pytest.skip("llvm-readelf / c++filt not available")
+    spec = importlib.util.spec_from_file_location("codeobj_stats", os.path.join(ROOT, "tools", "codeobj_stats.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    lib = os.path.join(ROOT, "tinman_sandbox_amd", "csrc", "libcaar_hip.so")
+    kernels = [k for _, blob in m.code_objects(lib) for k in m.kernels_of(blob)]
+    caar = [k for k in kernels if "caar_np" in k.get("name", "")]
+    np4 = [k for k in caar if "caar_np4" in k["name"]]
+    assert 40 <= len(np4) < 100, len(np4)
+    spilling = sorted(k["name"] for k in kernels if k["vgpr_spills"] or k["scratch_bytes"])
+    assert spilling == ["caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, true, 8, 33>"], spilling
+    # the default kernels of the BASELINE configurations and their step loops
+    by_name = {k["name"]: k for k in caar}
+    for name, lds_max in (("caar_np4_kernel<72, 5, 1, true, 2, 0, false, false, false, 8, 0>", 80 << 10),
+                          ("caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8, 27>", 80 << 10),
+                          ("caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, true, 2>", 160 << 10)):
+        k = by_name[name]
+        assert k["vgprs"] <= 256 and k["vgpr_spills"] == 0 and k["lds_bytes"] <= lds_max, k
+    assert any(n.startswith("caar_np4_steps_kernel<72,") for n in by_name) and any(n.startswith("caar_np8_steps_kernel<72,") for n in by_name)

@@ -596,7 +596,12 @@ static int launch_with(const CaarDims* dims, const CaarArrays* dev, const double
       if (!(measure ? adaptive_window_policy(dev, device, (hipStream_t)stream, &ev_before) : adaptive_window_current(dev, device))) {
         ch.cache_window = 0;
         const int twin = cfg->variants[ch.variant].streaming_twin;  // the all-streaming kernel of the same shape, if there is one
-        if (twin >= 0 && twin < cfg->count) ch.variant = twin;
+        if (twin >= 0 && twin < cfg->count) {
+          ch.variant = twin;
+          // ... with the element mapping the twin was measured faster with (round-robin for the all-streaming shapes),
+          // unless the host fixed the mapping (caar_set_xcd_chunked)
+          if (g_xcd_chunked.load(std::memory_order_relaxed) < 0) ch.xcd_chunked = cfg->variants[twin].prefers_xcd_chunked ? 1 : 0;
+        }
       }
     }
   }
