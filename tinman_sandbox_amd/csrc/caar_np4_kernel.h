@@ -164,7 +164,10 @@ struct Np4Lds {
   // the tracer block (4), handed from call to call in LDS ([slot][tile * 64 + lane]; each lane re-reads only what it wrote);
   // 2: the accumulators as well — vn0 (5, 6), omega_p (7), eta_dot_dpdn (8) — and pecnd (9): a steady call then touches no
   // element array in memory at all; 3: of those only vn0 and omega_p (where LDS has no room for all five: NLEV=128)
-  static constexpr int NCARRY = CARRY_LDS == 2 ? 10 : (CARRY_LDS == 3 ? 8 : (CARRY_LDS ? 5 : 1));
+  // 4: the nm1 state, vn0 and omega_p but NOT the tracer block (7 slots: with the NLEV=72 four-wave shape 80.2 KB per workgroup,
+  // the most that leaves room for two workgroups per CU) — the tracer block, pecnd (and nothing else) are read per call
+  static constexpr int NCARRY = CARRY_LDS == 2 ? 10 : (CARRY_LDS == 3 ? 8 : (CARRY_LDS == 4 ? 7 : (CARRY_LDS ? 5 : 1)));
+  static constexpr int ACC0 = CARRY_LDS == 4 ? 4 : 5;  // first accumulator slot
   double carry[NCARRY][CARRY_LDS ? NT_MAX * 64 : 1];
 };
 
@@ -201,6 +204,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   static_assert(!CARRY_LDS || STEPS, "CARRY_LDS: step loop only");
   static_assert(CARRY_IN == 0 || STEPS, "CARRY_IN: step loop only");
   static_assert(CARRY_LDS || (CARRY_IN & 6) == 0, "nm1 / tracer carry needs CARRY_LDS");
+  static_assert(CARRY_LDS != 4 || (CARRY_IN & 4) == 0, "CARRY_LDS == 4 does not carry the tracer block");
   static_assert(CARRY_LDS >= 2 || (CARRY_IN & 8) == 0, "accumulator carry needs CARRY_LDS >= 2");
   constexpr int carry_flags = CARRY_IN;
   constexpr bool carry_valid = STEPS && (CARRY_IN & 1);
@@ -332,7 +336,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   } else {
     in = load_n0((size_t)ie_s);
   }
-  if constexpr (CARRY_LDS && MOIST) {
+  if constexpr (CARRY_LDS && CARRY_LDS != 4 && MOIST) {
     if (!(carry_flags & 4)) {  // first call: the tracer block does not change from call to call (qn0 is fixed)
 #pragma unroll
       for (int r = 0; r < TPW; ++r)
@@ -402,7 +406,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         x.dpnm1 = stream_load<SNT>(dp_nm1 + off);
       }
       if (CARRY_LDS >= 2 && (carry_flags & 8)) {  // the previous call left the accumulators (2: and pecnd) in LDS
-        const lds_cptr ca = lds_reread_ptr(&lds.carry[CARRY_LDS >= 2 ? 5 : 0][0] + CAAR_TILE(r) * 64 + lane);
+        const lds_cptr ca = lds_reread_ptr(&lds.carry[CARRY_LDS >= 2 ? std::remove_reference<decltype(lds)>::type::ACC0 : 0][0] + CAAR_TILE(r) * 64 + lane);
         constexpr int Q = NT_MAX * 64;
         x.vn0.x = ca[0];
         x.vn0.y = ca[Q];
@@ -684,7 +688,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
         if ((!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(cur.eta)) && st_eta && eta_rmw)
           stream_store<ANT>(eta + off, e_new);
         if constexpr (CARRY_LDS >= 2) {
-          constexpr int A = CARRY_LDS >= 2 ? 5 : 0;
+          constexpr int A = CARRY_LDS >= 2 ? std::remove_reference<decltype(lds)>::type::ACC0 : 0;
           lds.carry[A][t * 64 + lane] = vn.x;
           lds.carry[A + 1][t * 64 + lane] = vn.y;
           lds.carry[A + 2][t * 64 + lane] = om_new;

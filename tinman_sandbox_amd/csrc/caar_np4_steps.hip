@@ -46,7 +46,7 @@ __device__ __forceinline__ void np4_step_loop(const KernelArgs& k0, int nsteps, 
   if (steady) {
     const int first_mask = ((!CARRY_LDS || nsteps <= 3) ? 1 : 0) | (nsteps == 1 ? 6 : 0);
     caar_np4_element<NLEV_T, TPW, MINW, MOIST, SNT, ANT, PF, false, false, false, 8, PARK, true, CARRY_LDS, 0, -1, WAVES>(args(), lds, &carry, first_mask);
-    constexpr int CIN = CARRY_LDS >= 2 ? 15 : (CARRY_LDS ? 7 : 1);
+    constexpr int CIN = CARRY_LDS == 4 ? 11 : (CARRY_LDS >= 2 ? 15 : (CARRY_LDS ? 7 : 1));
     // Between two calls: nothing a wave reads in LDS was written by another wave except the tile totals, and with state
     // carried in LDS (CARRY_LDS) those exist twice and alternate calls use alternate sets — a wave that is done with call s
     // starts call s+1 without waiting for the others (they meet at the barrier behind its first phase; by the time anyone
@@ -104,9 +104,19 @@ static hipError_t launch_np4_steps(const KernelArgs& k, int num_elems, int nstep
 }
 
 // the instantiations the variant tables of caar_np4.hip point to
+// What the NLEV=72 two-workgroup loop carries in LDS from call to call.  4 (default since round 4): the nm1 state AND the
+// accumulators vn0, omega_p — 7 slots, 80.2 KB per workgroup, the most that still lets two workgroups share a CU; a steady
+// call then reads only the tracer block and pecnd (18 KB per element instead of 64 KB read + written) and writes nothing.
+// 1 (rounds 3-4a): the nm1 state and the tracer block, the accumulators through the L2 / Infinity Cache.  Same speed with
+// the default cache policy (0.1046 against 0.1050 ms per call at 10 000 elements: the loop is bound by instruction issue and
+// latency at two waves per SIMD, not by memory) — but no longer dependent on it (the all-streaming loop: 0.1218 -> 0.1053) or
+// on what else uses the caches; bit-identical (profiles/r04/carry4_steps.log, carry4_bits.log).
+#ifndef CAAR_STEPS72_CARRY
+#define CAAR_STEPS72_CARRY 4
+#endif
 #define CAAR_STEPS(NLEV, TPW, MINW, POL, PF, PARK)                                                                  \
   hipError_t launch_np4_steps_##NLEV##_##POL(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) { \
-    return launch_np4_steps<NLEV, TPW, MINW, POL, PF, PARK>(k, num_elems, nsteps, rotate, s);                        \
+    return launch_np4_steps<NLEV, TPW, MINW, POL, PF, PARK, (NLEV == 72 ? CAAR_STEPS72_CARRY : (NLEV <= 80 ? 1 : 0))>(k, num_elems, nsteps, rotate, s); \
   }
 // NLEV=72: FOUR waves with 5, 5, 4, 4 of the 18 tiles (caar_np4_kernel.h UNEVEN), two workgroups per CU: the loop is bound by
 // instruction issue, and two 3 x 6 workgroups put 2, 2, 1, 1 waves on a CU's four SIMDs (12 tiles per pair of elements on
