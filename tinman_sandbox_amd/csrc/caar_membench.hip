@@ -155,8 +155,11 @@ __device__ __forceinline__ double2 ld2(const double2* p, bool) { return *p; }
 // 1 = stores array-major (one array's TPW tiles back to back = TPW x 512 B contiguous per wave and array: 3 KiB at
 // TPW = 6, 6 KiB for the (u, v) pairs), 2 = loads array-major as well.  Probes whether DRAM prefers longer bursts per
 // stream (round 2: write streams are what costs, profiles/r02/stream_probe_rw.log).
-template <int NLEV, int TPW, int NTL, int NTS, bool ALL_FIRST, int PP = 16, int WGW = 0, int ORDER = 0>
-__global__ __launch_bounds__((WGW ? WGW : NLEV * PP / 64 / TPW) * 64) void traffic_skeleton_np4(const KernelArgs k) {
+// ANTL / ANTS: the policy of the three read-modify-write accumulators (vn0, omega_p, eta_dot_dpdn), which the hybrid
+// form (traffic_skeleton_np4_hybrid) switches per element like the real kernel's hybrid cache policy does.
+template <int NLEV, int TPW, int NTL, int NTS, bool ALL_FIRST, int PP, int WGW, int ORDER, int ANTL, int ANTS>
+__device__ __forceinline__ void traffic_skeleton_body(const KernelArgs& k) {
+  static_assert(ORDER == 0 || (ANTL == NTL && ANTS == NTS), "array-major orders: one policy");
   constexpr int BLK = NLEV * PP;
   constexpr int WAVES = NLEV * PP / 64 / TPW;            // waves per element
   constexpr int WG_PER_ELEM = WGW ? WAVES / WGW : 1;
@@ -251,19 +254,19 @@ __global__ __launch_bounds__((WGW ? WGW : NLEV * PP / 64 / TPW) * 64) void traff
     a[r] = ld<NTL>(dp_n0 + off) + ld<NTL>(T_n0 + off) + ld<NTL>(Qdp + off) + ld<NTL>(pecnd + off) + g;
     uv[r] = ld<NTL>(reinterpret_cast<const v2*>(vv_n0) + off);
     um[r] = ld<NTL>(reinterpret_cast<const v2*>(vv_nm1) + off);
-    un[r] = ld<NTL>(reinterpret_cast<const v2*>(vvn0) + off);
+    un[r] = ld<ANTL>(reinterpret_cast<const v2*>(vvn0) + off);
     tn[r] = ld<NTL>(T_nm1 + off);
     dn[r] = ld<NTL>(dp_nm1 + off);
-    om[r] = ld<NTL>(omega_p + off);
-    et[r] = ld<NTL>(eta + off);
+    om[r] = ld<ANTL>(omega_p + off);
+    et[r] = ld<ANTL>(eta + off);
     if (!ALL_FIRST) {
       st<NTS>(reinterpret_cast<v2*>(vv_np1) + off, uv[r] + um[r]);
       st<NTS>(T_np1 + off, tn[r] + a[r]);
       st<NTS>(dp_np1 + off, dn[r] + a[r]);
       st<NTS>(phi + off, a[r]);
-      st<NTS>(omega_p + off, om[r] + a[r] * 0.0);
-      st<NTS>(reinterpret_cast<v2*>(vvn0) + off, un[r]);
-      st<NTS>(eta + off, et[r] + 0.0);
+      st<ANTS>(omega_p + off, om[r] + a[r] * 0.0);
+      st<ANTS>(reinterpret_cast<v2*>(vvn0) + off, un[r]);
+      st<ANTS>(eta + off, et[r] + 0.0);
     }
   }
   if (ALL_FIRST) {
@@ -274,12 +277,27 @@ __global__ __launch_bounds__((WGW ? WGW : NLEV * PP / 64 / TPW) * 64) void traff
       st<NTS>(T_np1 + off, tn[r] + a[r]);
       st<NTS>(dp_np1 + off, dn[r] + a[r]);
       st<NTS>(phi + off, a[r]);
-      st<NTS>(omega_p + off, om[r] + a[r] * 0.0);
-      st<NTS>(reinterpret_cast<v2*>(vvn0) + off, un[r]);
-      st<NTS>(eta + off, et[r] + 0.0);
+      st<ANTS>(omega_p + off, om[r] + a[r] * 0.0);
+      st<ANTS>(reinterpret_cast<v2*>(vvn0) + off, un[r]);
+      st<ANTS>(eta + off, et[r] + 0.0);
     }
   }
   if (w == 0 && lane < PP) eta_last[ulane] = eta_last[ulane] + 0.0;
+}
+
+template <int NLEV, int TPW, int NTL, int NTS, bool ALL_FIRST, int PP = 16, int WGW = 0, int ORDER = 0>
+__global__ __launch_bounds__((WGW ? WGW : NLEV * PP / 64 / TPW) * 64) void traffic_skeleton_np4(const KernelArgs k) {
+  traffic_skeleton_body<NLEV, TPW, NTL, NTS, ALL_FIRST, PP, WGW, ORDER, NTL, NTS>(k);
+}
+// The hybrid cache policy's traffic without its arithmetic: everything non-temporal except the accumulators of the
+// k.cache_count elements element_is_cached picks, which use the default policy (what the default NP=4 kernels do).
+// MINW: the register budget of the real kernel's launch shape, so that as many workgroups share a CU as there (2).
+template <int NLEV, int TPW, int MINW>
+__global__ __launch_bounds__(NLEV * 16 / 64 / TPW * 64, MINW) void traffic_skeleton_np4_hybrid(const KernelArgs k) {
+  const long long ie_s = element_of_block(k, blockIdx.x);
+  if (ie_s < 0) return;
+  if (element_is_cached(k, ie_s)) traffic_skeleton_body<NLEV, TPW, 1, 1, true, 16, 0, 0, 0, 0>(k);
+  else traffic_skeleton_body<NLEV, TPW, 1, 1, true, 16, 0, 0, 1, 1>(k);
 }
 
 // Same bytes as traffic_skeleton_np4<NLEV, 2, ...> but every access 16 bytes per lane: the two
@@ -372,6 +390,10 @@ hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, i
       case 25: hipLaunchKernelGGL((traffic_skeleton_np4<72, 9, 1, 1, true, 16, 0, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(128), 0, s, k); break;
       case 26: hipLaunchKernelGGL((traffic_skeleton_np4<72, 9, 1, 1, true, 16, 0, 2>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(128), 0, s, k); break;
       case 27: skel<72, 9, 1, 1, true>(k, num_elems, s); break;   // 2 waves x 9 tiles, tile-major (the comparator of 25/26)
+      // the HYBRID policy's traffic (round 4): the default kernel's cache policy and window, no arithmetic; 3 waves x 6 tiles
+      // (28) and 6 waves x 3 tiles (29) — the skeleton has no uneven 4-wave shape; both hold all loads of an element in flight
+      case 28: hipLaunchKernelGGL((traffic_skeleton_np4_hybrid<72, 6, 2>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(192), 0, s, k); break;
+      case 29: hipLaunchKernelGGL((traffic_skeleton_np4_hybrid<72, 3, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(384), 0, s, k); break;
       case 13: hipLaunchKernelGGL((traffic_skeleton_np4_w16<72, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(576), 0, s, k); break;
       case 14: hipLaunchKernelGGL((traffic_skeleton_np4_w16<72, 0>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(576), 0, s, k); break;
       default: return hipErrorInvalidValue;
