@@ -292,12 +292,14 @@ __global__ __launch_bounds__((WGW ? WGW : NLEV * PP / 64 / TPW) * 64) void traff
 // The hybrid cache policy's traffic without its arithmetic: everything non-temporal except the accumulators of the
 // k.cache_count elements element_is_cached picks, which use the default policy (what the default NP=4 kernels do).
 // MINW: the register budget of the real kernel's launch shape, so that as many workgroups share a CU as there (2).
-template <int NLEV, int TPW, int MINW>
-__global__ __launch_bounds__(NLEV * 16 / 64 / TPW * 64, MINW) void traffic_skeleton_np4_hybrid(const KernelArgs k) {
-  const long long ie_s = element_of_block(k, blockIdx.x);
+// WGW > 0: the element's waves spread over workgroups of WGW waves (as in traffic_skeleton_np4); AF: all loads first.
+template <int NLEV, int TPW, int MINW, int WGW = 0, bool AF = true>
+__global__ __launch_bounds__((WGW ? WGW : NLEV * 16 / 64 / TPW) * 64, MINW) void traffic_skeleton_np4_hybrid(const KernelArgs k) {
+  constexpr int WG_PER_ELEM = WGW ? NLEV * 16 / 64 / TPW / WGW : 1;
+  const long long ie_s = element_of_block(k, WGW ? blockIdx.x / WG_PER_ELEM : blockIdx.x);
   if (ie_s < 0) return;
-  if (element_is_cached(k, ie_s)) traffic_skeleton_body<NLEV, TPW, 1, 1, true, 16, 0, 0, 0, 0>(k);
-  else traffic_skeleton_body<NLEV, TPW, 1, 1, true, 16, 0, 0, 1, 1>(k);
+  if (element_is_cached(k, ie_s)) traffic_skeleton_body<NLEV, TPW, 1, 1, AF, 16, WGW, 0, 0, 0>(k);
+  else traffic_skeleton_body<NLEV, TPW, 1, 1, AF, 16, WGW, 0, 1, 1>(k);
 }
 
 // Same bytes as traffic_skeleton_np4<NLEV, 2, ...> but every access 16 bytes per lane: the two
@@ -394,6 +396,13 @@ hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, i
       // (28) and 6 waves x 3 tiles (29) — the skeleton has no uneven 4-wave shape; both hold all loads of an element in flight
       case 28: hipLaunchKernelGGL((traffic_skeleton_np4_hybrid<72, 6, 2>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(192), 0, s, k); break;
       case 29: hipLaunchKernelGGL((traffic_skeleton_np4_hybrid<72, 3, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(384), 0, s, k); break;
+      // hybrid, other shapes (plain element mapping): 18 / 9 one-wave workgroups per element, 9 two-wave ones, 3 x 6 tile by tile, 2 x 9, 9 x 2
+      case 30: hipLaunchKernelGGL((traffic_skeleton_np4_hybrid<72, 1, 1, 1>), dim3(num_elems * 18), dim3(64), 0, s, k); break;
+      case 31: hipLaunchKernelGGL((traffic_skeleton_np4_hybrid<72, 2, 1, 1>), dim3(num_elems * 9), dim3(64), 0, s, k); break;
+      case 32: hipLaunchKernelGGL((traffic_skeleton_np4_hybrid<72, 1, 1, 2>), dim3(num_elems * 9), dim3(128), 0, s, k); break;
+      case 33: hipLaunchKernelGGL((traffic_skeleton_np4_hybrid<72, 6, 2, 0, false>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(192), 0, s, k); break;
+      case 34: hipLaunchKernelGGL((traffic_skeleton_np4_hybrid<72, 9, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(128), 0, s, k); break;
+      case 35: hipLaunchKernelGGL((traffic_skeleton_np4_hybrid<72, 2, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(576), 0, s, k); break;
       case 13: hipLaunchKernelGGL((traffic_skeleton_np4_w16<72, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(576), 0, s, k); break;
       case 14: hipLaunchKernelGGL((traffic_skeleton_np4_w16<72, 0>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(576), 0, s, k); break;
       default: return hipErrorInvalidValue;
