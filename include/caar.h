@@ -306,7 +306,8 @@ long long caar_get_cache_window(void);
  * by HIP events that are polled, never waited for; after 48 calls, whenever the current policy's kernel time drifts up
  * by more than 3 %, and every 96 calls while the policy is all-streaming, the other policy runs for 7 calls and the
  * current one again for 7, and the faster becomes the policy (the window on ties).  Launches inside a stream capture,
- * on a sub-range, or through caar_run_steps' captured graph use the set's current policy and measure nothing.  Same
+ * on a sub-range, or through caar_run_steps' captured graph use the set's current policy and measure nothing; array sets
+ * whose traffic per call fits the 256 MB cache whole (up to ~1 250 elements at NP=4 NLEV=72) are not tuned at all.  Same
  * results either way (both policies are the same kernel).  caar_set_adaptive_window(0): the window always applies.
  * caar_adaptive_window_state: the policy in force for the array set whose derived_vn0 is `vn0_dev` (1 window, 0 all
  * streaming; -1 if the set is unknown) and, where the pointers are not NULL, the medians of the last probe (ms; 0 before

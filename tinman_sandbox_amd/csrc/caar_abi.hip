@@ -589,7 +589,10 @@ static int launch_with(const CaarDims* dims, const CaarArrays* dev, const double
   caar::LaunchChoice ch = forced ? *forced : caar::launch_choice(cfg);  // the knobs, read once
   // the adaptive window: whole-range launches of a hybrid kernel with a window to switch off (see adaptive_window_policy)
   hipEvent_t ev_before = nullptr;
-  if (cfg->variants[ch.variant].hybrid && ch.cache_window > 0 && p->rsplit != 0 && g_adaptive_window.load(std::memory_order_relaxed)) {
+  // (only where there is something to decide: a data set that fits the 256 MB cache whole is served from it under either
+  // policy, and the small-element hosts that live in the launch-latency regime are not charged the tuner's microseconds)
+  if (cfg->variants[ch.variant].hybrid && ch.cache_window > 0 && p->rsplit != 0 && g_adaptive_window.load(std::memory_order_relaxed) &&
+      caar_algorithmic_bytes(dims->np, dims->nlev, 0) * (long long)dims->num_elems > (256LL << 20)) {
     int device = 0;
     if (hipGetDevice(&device) == hipSuccess) {
       const bool measure = tune && n == dims->num_elems;  // else: the set's current policy, nothing measured
