@@ -76,6 +76,23 @@ def test_single_gpu_line_carries_the_contract_and_the_host_sequences():
         # the step-loop kernel's own HBM bytes per call, from the same counter passes: below a single call's, below the peak
         assert 0 < rr["hbm_bytes_per_call"] < roof["traffic"] and 0 < rr["hbm_frac_of_peak"] < 1.0
         assert "steps_kernel" in rr["hbm_kernel"]
+    # no figure of the line exceeds a physical peak: every bandwidth-like field is <= the 8 TB/s HBM peak, every
+    # fraction-like field <= 1.2 (the Infinity-Cache-assisted algorithmic rates may pass 1.0 of a measured copy, never the peak)
+    def walk(o, path=""):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                walk(v, path + "/" + k)
+        elif isinstance(o, list):
+            for i, v in enumerate(o):
+                walk(v, path + "[%d]" % i)
+        elif isinstance(o, (int, float)) and not isinstance(o, bool):
+            key = path.rsplit("/", 1)[-1].split("[")[0]
+            if key.endswith("GBs") or key in ("achieved_all_streaming", "achieved_interleaved", "achieved_interleaved_evicting"):
+                assert o <= 8000.0, (path, o)
+            if key.startswith("frac") and "copy" not in key and "skeleton" not in key:
+                assert o <= 1.0, (path, o)
+    walk(j)
+    assert roof["dram_estimate"]["frac"] < roof["frac"] <= 1.0
     cb = j["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
     # SURVEY 8d / BASELINE.md section 4: CPU model, nproc, flags, and a one-core leg on the whole data set (>= 3 timed calls)

@@ -37,7 +37,13 @@ LIB_DEBUG = os.path.join(CSRC, "libcaar_hip_debug.so")
 DEBUG_SOURCES = ("caar_np4.hip", "caar_np4_steps.hip", "caar_np8.hip", "caar_abi.hip")
 
 
-def build_library(force=False, verbose=False, jobs=4, debug=False):
+LIB_EXTRA = os.path.join(CSRC, "libcaar_hip_extra.so")
+# the translation units -DCAAR_EXTRA_NLEV=1 changes (csrc/caar_kernel_args.h: launch shapes specialised for seven more level
+# counts, their step loops, the Eulerian form beyond 128 levels — not SURVEY section 8 rows, kept out of the default library)
+EXTRA_SOURCES = ("caar_np4.hip", "caar_np4_steps.hip", "caar_abi.hip")
+
+
+def build_library(force=False, verbose=False, jobs=4, debug=False, extra=False):
     """One object per .hip source (only stale ones are recompiled, `jobs` at a time), then one
     link: editing one kernel file costs one compile, not seven.  debug: libcaar_hip_debug.so, the same
     library with the kernels compiled with -DCAAR_DEBUG (the reference's check_dp3d as a device-side
@@ -48,13 +54,14 @@ def build_library(force=False, verbose=False, jobs=4, debug=False):
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
-    LIB = LIB_DEBUG if debug else globals()["LIB"]
+    LIB = LIB_DEBUG if debug else (LIB_EXTRA if extra else globals()["LIB"])
 
     def compile_one(name):
         dbg = debug and name in DEBUG_SOURCES
-        src, obj = os.path.join(CSRC, name), os.path.join(objdir, name.replace(".hip", ".debug.o" if dbg else ".o"))
+        ext = extra and name in EXTRA_SOURCES
+        src, obj = os.path.join(CSRC, name), os.path.join(objdir, name.replace(".hip", ".debug.o" if dbg else (".extra.o" if ext else ".o")))
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc()] + flags + (["-DCAAR_DEBUG"] if dbg else []) + ["-c", src, "-o", obj]
+            cmd = [hipcc()] + flags + (["-DCAAR_DEBUG"] if dbg else []) + (["-DCAAR_EXTRA_NLEV=1"] if ext else []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
@@ -123,6 +130,7 @@ def build_all(force=False, verbose=False, debug=True):
     lib = build_library(force, verbose)
     if debug:
         build_library(force, verbose, debug=True)
+        build_library(force, verbose, extra=True)   # libcaar_hip_extra.so: the -DCAAR_EXTRA_NLEV=1 build, so that what it holds stays tested
     for np_, nlev in ((4, 72), (4, 128), (8, 72)):
         build_host_driver(force, verbose, np_, nlev)
     build_fortran_driver(force, verbose)

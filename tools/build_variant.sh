@@ -8,7 +8,7 @@ C=$(cd "$(dirname "$0")/../tinman_sandbox_amd/csrc" && pwd)
 T=$(mktemp -d /tmp/caar_variant.XXXXXX)
 OBJS=""
 for f in $C/build/*.o; do
-  case "$f" in *.debug.o) continue;; esac
+  case "$f" in *.debug.o|*.extra.o) continue;; esac
   b=$(basename $f .o); skip=0
   for tu in "$@"; do [ "$b" = "$(basename $tu .hip)" ] && skip=1; done
   [ $skip = 0 ] && OBJS="$OBJS $f"
