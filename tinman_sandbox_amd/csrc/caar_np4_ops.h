@@ -117,6 +117,9 @@ __device__ __forceinline__ int mfma4_level(int lane) { return (lane >> 2) & 3; }
 #ifndef CAAR_NP4_DB_DPP
 #define CAAR_NP4_DB_DPP 0
 #endif
+#ifndef CAAR_NP4_DB_SPREAD
+#define CAAR_NP4_DB_SPREAD 0
+#endif
 struct Mfma4Ctx {
   double d_hl;  // Dvv[h][l] for lane = 16h + 4blk + l: A operand of da, B operand of db
   double d_lh;  // Dvv[l][h]: A operand of wa, B operand of wb
@@ -130,7 +133,11 @@ __device__ __forceinline__ Mfma4Ctx make_mfma4_ctx(const double* dvv /* Dvv[k][j
   Mfma4Ctx c;
   c.d_hl = dvv[h * 4 + l];
   c.d_lh = dvv[l * 4 + h];
+#if CAAR_NP4_DB_SPREAD
+  c.src_t = 16 * l + 4 * blk + (l >= 2 ? (h ^ 2) : h);
+#else
   c.src_t = 16 * l + 4 * blk + h;
+#endif
 #if CAAR_NP4_DB_DPP
   for (int k = 0; k < 4; ++k) c.cb[k] = dvv[k * 4 + l];
 #endif
@@ -147,13 +154,29 @@ __device__ __forceinline__ double mfma4_d_db(const Mfma4Ctx& c, double f) {
   s = __builtin_fma(c.cb[2], dpp<0xAA>(f), s);
   return __builtin_fma(c.cb[3], dpp<0xFF>(f), s);
 }
+#elif CAAR_NP4_DB_SPREAD
+// (experiment, -DCAAR_NP4_DB_SPREAD=1) rows 2, 3 swap the lane pairs of every quad first (quad_perm [2,3,0,1], row_mask 0xC), so
+// that the 32 lanes of a ds_bpermute group fetch from lanes on 32 different banks (as it stands rows l and l + 2 collide: 2
+// extra LDS cycles each, the 360 SQ_LDS_BANK_CONFLICT cycles per element-call that are left at NLEV=72).  Bit-identical, and
+// not adopted: single call equal (86.3-87.2 against 86.6-87.5 %), step loop 0.1084 against 0.1044 ms per call — the extra move
+// sits in front of the transpose in a dependent chain, and the conflict cycles it removes were not on anybody's critical path
+// (profiles/r04/spread4_*.log; the same finding as for NP=8, caar_np8_ops.h).
+__device__ __forceinline__ double mfma4_d_db(const Mfma4Ctx& c, double f) {
+  f = __builtin_amdgcn_update_dpp(f, f, 0x4E, 0xC, 0xf, false);
+  return mfma4x4(__shfl(f, c.src_t, 64), c.d_hl);
+}
 #else
 __device__ __forceinline__ double mfma4_d_db(const Mfma4Ctx& c, double f) { return mfma4x4(__shfl(f, c.src_t, 64), c.d_hl); }
 #endif
 // sum_k Dvv[a][k] f[k][b]
 __device__ __forceinline__ double mfma4_w_a(const Mfma4Ctx& c, double f) { return mfma4x4(c.d_lh, f); }
 // sum_k Dvv[b][k] f[a][k]
-__device__ __forceinline__ double mfma4_w_b(const Mfma4Ctx& c, double f) { return mfma4x4(__shfl(f, c.src_t, 64), c.d_lh); }
+__device__ __forceinline__ double mfma4_w_b(const Mfma4Ctx& c, double f) {
+#if CAAR_NP4_DB_SPREAD
+  f = __builtin_amdgcn_update_dpp(f, f, 0x4E, 0xC, 0xf, false);
+#endif
+  return mfma4x4(__shfl(f, c.src_t, 64), c.d_lh);
+}
 
 // one name for both forms' coefficient set-up (the kernels pick the form at compile time)
 __device__ __forceinline__ void make_np4_ctx(RowCoef& c, const double* dvv, int lane) { c = make_row_coef(dvv, lane); }
