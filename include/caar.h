@@ -304,7 +304,7 @@ long long caar_get_cache_window(void);
  * stream), and -2 % when a neighbour with the default cache policy has evicted them.  The library therefore measures:
  * per array set (keyed on elem_derived_vn0), whole-range launches of a hybrid-policy kernel are now and then bracketed
  * by HIP events that are polled, never waited for; after 48 calls, whenever the current policy's kernel time drifts up
- * by more than 3 %, and every 96 calls while the policy is all-streaming, the other policy runs for 7 calls and the
+ * by more than 3 %, every 96 calls while the policy is all-streaming and every 4 096 while it is the window, the other policy runs for 7 calls and the
  * current one again for 7, and the faster becomes the policy (the window on ties).  Launches inside a stream capture,
  * on a sub-range, or through caar_run_steps' captured graph use the set's current policy and measure nothing; array sets
  * whose traffic per call fits the 256 MB cache whole (up to ~1 250 elements at NP=4 NLEV=72) are not tuned at all.  Same

@@ -179,7 +179,8 @@ static LaunchChoice launch_choice(const Config* cfg) {
 // AND what it does to the neighbour that follows (under eviction the window-policy kernel itself is the faster one, 0.336
 // against 0.351 ms, and the neighbour pays for writing its dirty lines back: timing the kernel alone picks the wrong side).
 //   * After kFirstProbe calls, whenever the current policy's call-to-call time drifts up by more than kDrift (the host's
-//     pattern changed), and every kReprobe calls while the current policy is all-streaming (trying the window is cheap),
+//     pattern changed), every kReprobe calls while the current policy is all-streaming (trying the window is cheap) and every
+//     kReprobeWindow calls while it is the window,
 //     the other policy runs for kWarm + kMeas calls, then the current one again for kWarm + kMeas, and the faster (medians
 //     of the measured calls; the window on ties) becomes the policy.
 //   * A launch inside a stream capture, on a sub-range of the elements, or of a captured graph uses the set's current
@@ -187,7 +188,7 @@ static LaunchChoice launch_choice(const Config* cfg) {
 // Both policies are the same kernel (cache_count == 0 is all-streaming) and give identical results.
 namespace caar {
 struct WindowTuner {
-  static constexpr int kFirstProbe = 48, kWarm = 3, kMeas = 4, kHalf = kWarm + kMeas, kReprobe = 96, kSampleEvery = 8;
+  static constexpr int kFirstProbe = 48, kWarm = 3, kMeas = 4, kHalf = kWarm + kMeas, kReprobe = 96, kReprobeWindow = 4096, kSampleEvery = 8;
   static constexpr int kProbeEvents = 2 * kHalf + 1;  // one in front of every probe call + one in front of the call after
   static constexpr double kDrift = 0.03, kTie = 0.003;
   const void* key = nullptr;  // CaarArrays::elem_derived_vn0 of the set
@@ -315,7 +316,9 @@ static int adaptive_window_policy(const CaarArrays* dev, int device, hipStream_t
   if (t->step == 0) {
     const bool first = t->probes == 0 && t->calls == WindowTuner::kFirstProbe;
     const bool drift = t->probes > 0 && t->base_ms > 0.0 && t->cur_ms > t->base_ms * (1.0 + WindowTuner::kDrift) && t->since_decision > 24;
-    const bool again = t->probes > 0 && !t->use_window && t->since_decision >= WindowTuner::kReprobe;
+    // (while the window is the policy a re-probe costs seven all-streaming calls, so it is rare: it only guards against a
+    // first probe that was taken during a fresh process's ramp-up, which favours whichever policy ran second)
+    const bool again = t->probes > 0 && t->since_decision >= (t->use_window ? WindowTuner::kReprobeWindow : WindowTuner::kReprobe);
     if (first || drift || again) {
       t->step = 1;
       t->sample = 0;
