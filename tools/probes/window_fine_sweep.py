@@ -13,11 +13,11 @@ def timed(data, n=40):
         b.record(); torch.cuda.synchronize()
         best = min(best, a.elapsed_time(b) / n)
     return best
-for nlev, E in ((72, 10000), (72, 12500), (128, 12500)):
+for nlev, E in ((72, 10000), (72, 12500), (72, 15000), (72, 20000), (128, 12500), (128, 8000)):
     data = tsa.TestData().init_data(E, 4, nlev, device="cuda")
-    for rep in range(2):
+    for rep in range(1):
         row = []
-        for mb in (192, 208, 216, 224, 232, 240, 248):
+        for mb in (176, 192, 200, 208, 216, 224, 232, 240):
             lib.caar_set_cache_window(mb << 20)
             row.append("%dMB %.4f" % (mb, timed(data)))
         print("nlev=%d E=%d: " % (nlev, E) + " | ".join(row), flush=True)
