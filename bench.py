@@ -206,6 +206,9 @@ def measure_config(np_, nlev, elems, steps, warmup):
             "frac_of_hbm_peak": roof["frac"], "achieved_all_streaming_GBs": roof.get("achieved_all_streaming"),
             "algorithmic_bytes_per_element": roof["algorithmic_bytes_per_element"], "kernel": j["config"]["kernel"],
             "run_steps": roof.get("run_steps"),
+            # the kernel against its own arithmetic-free traffic (same bytes, same cache policy), measured in that process
+            "traffic_skeleton_own_policy_GBs": roof.get("traffic_skeleton_own_policy_GBs"),
+            "frac_of_own_traffic_skeleton": roof.get("frac_of_own_traffic_skeleton"),
             "measured_in": "child process: " + " ".join(cmd[1:])}
 
 
@@ -266,6 +269,32 @@ def measured_ceilings(tsa, torch, dev, np_, nlev, elems):
         del data
     torch.cuda.empty_cache()
     return out
+
+
+def own_traffic_skeleton(tsa, torch, data, dev, np_, nlev, elems):
+    """The configuration's kernel against ITS OWN traffic with the arithmetic taken out (caar_traffic_skeleton: the same
+    bytes, addressing and cache policy — NP=4: the hybrid policy with the current window, replayed like the kernel, variants
+    28 / 29; NP=8: all-streaming, the kernel's 8 x 9 shape, variants 0 / 2) on the arrays of this process: GB/s of the best
+    variant, or None where there is no skeleton for the configuration."""
+    import ctypes as C
+    L = tsa.library()
+    st = torch.cuda.current_stream(dev)
+    variants = (28, 29) if (np_ == 4 and nlev in (72, 128)) else ((0, 2) if (np_ == 8 and nlev == 72) else ())
+    dims, ptrs, prm = data.arrays.dims(), data.arrays.pointers(), data.params()
+    best = None
+    for v in variants:
+        call = lambda: L.check(L.lib.caar_traffic_skeleton(C.byref(dims), C.byref(ptrs), C.byref(prm), v, C.c_void_p(st.cuda_stream)), "skeleton")  # noqa: E731
+        for _ in range(4):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(20):
+            call()
+        e1.record(st)
+        torch.cuda.synchronize(dev)
+        gbs = tsa.algorithmic_bytes(np_, nlev) * elems / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e9
+        best = gbs if best is None else max(best, gbs)
+    return best
 
 
 def static_traffic(np_, nlev, elems):
@@ -983,6 +1012,12 @@ def main():
             if roof["measured_on_this_box"].get("traffic_skeleton_hybrid_GBs"):
                 # the kernel against its own traffic with no arithmetic (same cache policy, same window, same replay)
                 roof["frac_of_hybrid_traffic_skeleton"] = roof["achieved"] / roof["measured_on_this_box"]["traffic_skeleton_hybrid_GBs"]
+        if world == 1 and args.no_other_configs and "measured_on_this_box" not in roof:
+            # (a child of measure_config, or a run without the ceilings leg: still the kernel against its own skeleton)
+            sk = own_traffic_skeleton(tsa, torch, data, dev, args.np_, args.nlev, mine)
+            if sk:
+                roof["traffic_skeleton_own_policy_GBs"] = sk
+                roof["frac_of_own_traffic_skeleton"] = roof["achieved"] / sk
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.np_, args.nlev, args.cpu_seconds, mine)
         print(json.dumps(out))

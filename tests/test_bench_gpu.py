@@ -93,6 +93,8 @@ def test_single_gpu_line_carries_the_contract_and_the_host_sequences():
                 assert o <= 1.0, (path, o)
     walk(j)
     assert roof["dram_estimate"]["frac"] < roof["frac"] <= 1.0
+    # the kernel against its own traffic with the arithmetic taken out (same bytes, same cache policy, same arrays)
+    assert roof["traffic_skeleton_own_policy_GBs"] > 0 and 0.5 < roof["frac_of_own_traffic_skeleton"] < 1.5
     cb = j["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
     # SURVEY 8d / BASELINE.md section 4: CPU model, nproc, flags, and a one-core leg on the whole data set (>= 3 timed calls)

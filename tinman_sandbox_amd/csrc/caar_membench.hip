@@ -413,6 +413,9 @@ hipError_t launch_traffic_skeleton(const KernelArgs& k, int nlev, int variant, i
       case 1: skel<128, 2, 0, 0, false>(k, num_elems, s); break;
       case 2: skel<128, 4, 1, 1, false>(k, num_elems, s); break;
       case 3: skel<128, 4, 0, 0, true>(k, num_elems, s); break;
+      // the HYBRID policy's traffic (round 4), NLEV=128: 4 waves x 8 tiles (the default kernel's shape) and 8 x 4
+      case 28: hipLaunchKernelGGL((traffic_skeleton_np4_hybrid<128, 8, 2>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(256), 0, s, k); break;
+      case 29: hipLaunchKernelGGL((traffic_skeleton_np4_hybrid<128, 4, 1>), dim3(k.per_xcd ? 8 * k.per_xcd : num_elems), dim3(512), 0, s, k); break;
       default: return hipErrorInvalidValue;
     }
   } else {
