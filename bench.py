@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-interleaved", action="store_true",
                     help="skip the host-sequence measurements (roofline.interleaved: CAAR alternated with a tracer step / "
                          "a cache-evicting kernel, time levels rotating)")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the `dropin` object (the reference driver's loop through Homme::compute_and_apply_rhs(TestData&) "
+                         "on host-owned arrays, mapped and resident mode, in child processes)")
     ap.add_argument("--no-spinup", action="store_true",
                     help="skip the untimed device spin-up before the W warmup steps: the timed steps then run on a "
                          "device that is still ramping up (fresh process: clocks, TLBs, cache window; ~25 ms)")
@@ -72,17 +75,25 @@ def parse():
     return ap.parse_args()
 
 
-def host_cores():
-    """Host threads the CPU baseline may use: the affinity mask, cut to the cgroup CPU
-    quota when there is one and to the GPU box's per-GPU CPU share (16; override with
-    CAAR_BENCH_CORES)."""
-    n = len(os.sched_getaffinity(0))
+def cgroup_cpu_quota():
+    """CPUs' worth of run time the cgroup grants this job (cpu.max quota / period), or None if unlimited / unreadable."""
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
+            return int(quota) / int(period)
     except (OSError, ValueError):
         pass
+    return None
+
+
+def host_cores():
+    """Host threads the CPU baseline uses: the affinity mask, cut to the cgroup CPU
+    quota when there is one and to the GPU box's per-GPU CPU share (16; override with
+    CAAR_BENCH_CORES)."""
+    n = len(os.sched_getaffinity(0))
+    q = cgroup_cpu_quota()
+    if q is not None:
+        n = min(n, max(1, int(q)))
     return max(1, min(n, int(os.environ.get("CAAR_BENCH_CORES", "16"))))
 
 
@@ -120,9 +131,9 @@ def cpu_baseline(np_, nlev, seconds, elems=10000):
         arrs = O.init_arrays(np_, nlev, 1, 3, ne)
         if use_ref:
             R = po.Reference(np_, nlev)
-            return lambda: R.compute_and_apply_rhs(arrs, Dvv, sc)
+            return lambda reps=1: R.compute_and_apply_rhs(arrs, Dvv, sc, reps)
         o = po.Oracle()
-        return lambda: o.compute_and_apply_rhs(arrs, Dvv, sc)
+        return lambda reps=1: o.compute_and_apply_rhs(arrs, Dvv, sc, reps)
 
     # (a) one core, the full data set
     run = make_runner(elems)
@@ -135,29 +146,48 @@ def cpu_baseline(np_, nlev, seconds, elems=10000):
     del run
     one_med = sorted(one)[1]
 
-    # (b) all cores: slabs of the same data set
-    per_thread = -(-elems // cores)
-    reps = max(3, int(round(seconds / (one_med * per_thread / elems))))
-    runners = [make_runner(per_thread) for _ in range(cores)]
-    for r in runners:
-        r()  # warm-up call (touches the memory)
-    barrier = threading.Barrier(cores + 1)
+    # (b) `cores` threads: slabs of the same data set
+    def threaded(nthreads):
+        per_thread = -(-elems // nthreads)
+        reps = max(3, int(round(seconds / (one_med * per_thread / elems))))
+        runners = [make_runner(per_thread) for _ in range(nthreads)]
+        for r in runners:
+            r()  # warm-up call (touches the memory)
+        barrier = threading.Barrier(nthreads + 1)
 
-    def work(r):
-        barrier.wait()
-        for _ in range(reps):
-            r()
-        barrier.wait()
+        def work(r):
+            barrier.wait()
+            r(reps)   # the reps calls are one C call (the reference driver's loop): no Python between them, the GIL released
+            barrier.wait()
 
-    ths = [threading.Thread(target=work, args=(r,)) for r in runners]
-    for t in ths:
-        t.start()
-    barrier.wait()
-    t0 = time.perf_counter()
-    barrier.wait()
-    wall = time.perf_counter() - t0
-    for t in ths:
-        t.join()
+        ths = [threading.Thread(target=work, args=(r,)) for r in runners]
+        for t in ths:
+            t.start()
+        barrier.wait()
+        t0 = time.perf_counter()
+        barrier.wait()
+        wall = time.perf_counter() - t0
+        for t in ths:
+            t.join()
+        return per_thread, reps, wall
+
+    per_thread, reps, wall = threaded(cores)
+    # (c) every hardware thread of the affinity mask (the whole box, not the per-GPU share), same protocol.  Where the job
+    # runs under a cgroup CPU quota (the GPU pool's boxes: 16 CPUs' worth for a one-GPU job) the threads beyond the quota
+    # only time-share it: the figure is then what THIS JOB may use of the box, stated as such.
+    all_n = len(os.sched_getaffinity(0))
+    quota = cgroup_cpu_quota()
+    if all_n > cores:
+        a_per, a_reps, a_wall = threaded(all_n)
+        all_threads = {"value": all_n * a_per * a_reps / a_wall, "cores": all_n, "elements_per_thread": a_per, "calls": a_reps,
+                       "wall_seconds": a_wall, "cgroup_cpu_quota": quota,
+                       "note": ("%d threads time-sharing a cgroup quota of %.1f CPUs: not a whole-box figure, none can be measured "
+                                "from inside this job" % (all_n, quota)) if quota is not None and quota < all_n else
+                               "every hardware thread in the affinity mask; an 8-GPU node shares them between its 8 GPUs, so "
+                               "the per-GPU comparison is `value` (%d threads)" % cores}
+    else:
+        all_threads = {"value": None, "cores": all_n, "cgroup_cpu_quota": quota,
+                       "note": "the affinity mask holds no more threads than `cores`"}
     balg = 8 * (21 * np_ * np_ * nlev + 2 * np_ * np_ * (nlev + 1) + 13 * np_ * np_)
     what = "oracle/_ref (reference cxx/pointers_only)" if use_ref else "oracle/caar_oracle.c"
     value = cores * per_thread * reps / wall
@@ -176,6 +206,7 @@ def cpu_baseline(np_, nlev, seconds, elems=10000):
                         "seconds_per_call": one, "algorithmic_GBs": elems / one_med * balg / 1e9,
                         "min_seconds": min(one), "median_seconds": one_med},
         "single_core_value": elems / one_med,
+        "all_threads": all_threads,
         "sample": "all cores: %d threads x %d elements (slabs of the %d-element data set) x %d calls of %s, NP=%d NLEV=%d, "
                   "wall %.2fs; one core: %d elements x 3 calls (median %.3fs)" % (
                       cores, per_thread, elems, reps, what, np_, nlev, wall, elems, one_med),
@@ -190,7 +221,7 @@ def measure_config(np_, nlev, elems, steps, warmup):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--np", str(np_), "--nlev", str(nlev),
            "--elems-per-gpu", str(elems), "--steps", str(steps), "--warmup", str(warmup), "--no-other-configs",
-           "--no-cpu-baseline", "--no-interleaved", "--no-live-traffic"]
+           "--no-cpu-baseline", "--no-interleaved", "--no-live-traffic", "--no-dropin"]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
@@ -666,6 +697,51 @@ def run_steps_leg(tsa, torch, args, data, dev, stream, mine, calls=STEP_CALLS):
     return out
 
 
+def dropin_leg(np_, nlev, elems, kernel_ms, timeout=300):
+    """The literal drop-in: the reference driver's loop (main.cpp:113-121) calling Homme::compute_and_apply_rhs(TestData&)
+    on arrays the HOST owns, through this repo's shim (tinman_sandbox_amd/host/homme_caar.cpp, the file the reference's
+    unchanged main.cpp links against: oracle/Makefile pointers_only_hip) — run by this repo's own driver binary
+    (host/caar_driver --tinman-host-arrays=yes: the same shim, the same loop) in two child processes:
+      mapped    the default: the kernel works on the page-locked host arrays over PCIe, synchronous per call;
+      resident  CAAR_SHIM_RESIDENT=1: uploaded at the first call, later calls only enqueue the kernel.
+    ms per call excludes the first call's page-locking / upload (Homme::shim_stats).  Outside `value`."""
+    import re
+    import subprocess
+    suffix = "" if (np_, nlev) == (4, 72) else "_np%d_nlev%d" % (np_, nlev)
+    exe = os.path.join(ROOT, "tinman_sandbox_amd", "host", "caar_driver" + suffix)
+    if not os.path.exists(exe):
+        return {"error": "host/caar_driver%s is not built" % suffix}
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "CAAR_SHIM_RESIDENT"):
+        env.pop(k, None)
+    out = {"driver": "tinman_sandbox_amd/host/caar_driver%s --tinman-host-arrays=yes (Homme::compute_and_apply_rhs(TestData&) in the "
+                     "reference's loop, main.cpp:113-121)" % suffix, "elements": elems}
+    norms = {}
+    for mode, calls, extra in (("mapped", 12, []), ("resident", 400, ["--tinman-resident=yes"])):
+        cmd = [exe, "--tinman-num-elems=%d" % elems, "--tinman-num-exec=%d" % calls, "--tinman-host-arrays=yes"] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        except subprocess.TimeoutExpired:
+            out[mode] = {"error": "timeout"}
+            continue
+        m = re.search(r"shim_stats mode=(\w+) calls=(\d+) seconds=([-+0-9.eE]+) wall=([-+0-9.eE]+)", r.stdout)
+        if r.returncode != 0 or not m or m.group(1) != mode:
+            out[mode] = {"error": (r.stderr or r.stdout)[-300:]}
+            continue
+        n, secs = int(m.group(2)), float(m.group(3))
+        ms = 1e3 * secs / n
+        out[mode] = {"calls": n, "ms_per_call": ms, "element_updates_per_s": elems / (ms * 1e-3),
+                     "over_kernel_ms": ms / kernel_ms if kernel_ms else None,
+                     "loop_wall_seconds_incl_first_call": float(m.group(4))}
+        norms[mode] = re.findall(r"\|\|(?:v|T|dp)\|\|_2\s*=\s*([-+0-9.eE]+)", r.stdout)[-3:]
+    if len(norms) == 2:
+        out["final_norms_equal_digit_for_digit"] = norms["mapped"] == norms["resident"]
+    out["note"] = ("mapped is PCIe-bound by construction (every input byte crosses the link once per call); resident runs the "
+                   "kernel of `value` behind the reference's signature; the first ~60 launches of the fresh child process ramp up "
+                   "(roofline.spinup), which its %d calls include" % 400)
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: this process starts the N ranks itself and only
     waits for them.  It imports neither torch nor the library, so nothing here has initialised the GPU (no exec of an
@@ -1019,6 +1095,8 @@ def main():
             # (measured_on_this_box.traffic_skeleton_hybrid_GBs is the hybrid skeleton on a FRESH allocation made at the end of
             # this process: placement differs from the timed arrays' by up to 5 %; the like-for-like ratio is
             # roofline.frac_of_own_traffic_skeleton, measured on the timed arrays themselves)
+        if world == 1 and not args.no_dropin and not args.no_other_configs:
+            out["dropin"] = dropin_leg(args.np_, args.nlev, mine, kernel_ms_max)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.np_, args.nlev, args.cpu_seconds, mine)
         print(json.dumps(out))

@@ -200,6 +200,12 @@ static void oracle_eulerian_vertical(int np, int nlev, const double *divdp, cons
   }
 }
 
+int oracle_compute_and_apply_rhs_repeat(const oracle_arrays *a, const oracle_params *c, int reps) {
+  int rc = 0;
+  for (int i = 0; i < reps && rc == 0; ++i) rc = oracle_compute_and_apply_rhs(a, c);
+  return rc;
+}
+
 /* P:15-278. */
 int oracle_compute_and_apply_rhs(const oracle_arrays *a, const oracle_params *c) {
   const int np = c->np, nlev = c->nlev, tl = c->timelevels, qd = c->qsize_d;

@@ -98,6 +98,8 @@ void oracle_preq_omega_ps(int np, int nlev, const double *p,
 /* compute_and_apply_rhs.cpp:15-278 / routine_mod.F90:7-193.
  * Returns 0, or -1 if scratch allocation failed. */
 int oracle_compute_and_apply_rhs(const oracle_arrays *a, const oracle_params *p);
+/* `reps` back-to-back calls (the reference driver's loop, main.cpp:113-121); stops at the first non-zero return. */
+int oracle_compute_and_apply_rhs_repeat(const oracle_arrays *a, const oracle_params *p, int reps);
 
 /* Kahan 2-norm, compute_and_apply_rhs.cpp:353-370 / utils_mod.F90:9-30 */
 double oracle_compute_norm(const double *field, long length);

@@ -105,6 +105,8 @@ class Oracle:
         L = self.lib = C.CDLL(path)
         L.oracle_compute_and_apply_rhs.argtypes = [C.POINTER(_OracleArrays), C.POINTER(_OracleParams)]
         L.oracle_compute_and_apply_rhs.restype = C.c_int
+        L.oracle_compute_and_apply_rhs_repeat.argtypes = [C.POINTER(_OracleArrays), C.POINTER(_OracleParams), C.c_int]
+        L.oracle_compute_and_apply_rhs_repeat.restype = C.c_int
         L.oracle_state_norms.argtypes = [C.POINTER(_OracleArrays), C.POINTER(_OracleParams), _dp]
         L.oracle_compute_norm.argtypes = [_dp, C.c_long]
         L.oracle_compute_norm.restype = C.c_double
@@ -149,9 +151,10 @@ class Oracle:
                              float(sc["hyai"][0]), _ptr(self._keep), rsplit,
                              _ptr(self._hybi) if rsplit == 0 else None)
 
-    def compute_and_apply_rhs(self, arrs, Dvv, sc):
+    def compute_and_apply_rhs(self, arrs, Dvv, sc, reps=1):
+        """reps > 1: that many back-to-back calls inside ONE C call (no Python, no GIL between calls)."""
         a, p = self._arrays(arrs), self._params(arrs, Dvv, sc)
-        rc = self.lib.oracle_compute_and_apply_rhs(C.byref(a), C.byref(p))
+        rc = self.lib.oracle_compute_and_apply_rhs_repeat(C.byref(a), C.byref(p), int(reps))
         if rc != 0:
             raise RuntimeError("oracle_compute_and_apply_rhs rc=%d" % rc)
 
@@ -302,6 +305,9 @@ class Reference:
         self.qsize_d, self.timelevels = dims[2], dims[3]
         pp = _dp * 16
         L.ref_compute_and_apply_rhs.argtypes = ([pp] + [C.c_int] * 6 + [C.c_double] * 7 + [_dp, _dp])
+        self.has_repeat = hasattr(L, "ref_compute_and_apply_rhs_repeat")  # (libraries built before round 5 lack it)
+        if self.has_repeat:
+            L.ref_compute_and_apply_rhs_repeat.argtypes = L.ref_compute_and_apply_rhs.argtypes + [C.c_int]
         L.ref_init_data.argtypes = [C.c_int, pp, _dp, _dp, _dp]
         L.ref_sphere_operator.argtypes = [C.c_int, _dp, _dp, pp, C.c_int, C.c_double, _dp]
         L.ref_compute_norm.argtypes = [_dp, C.c_int]
@@ -311,16 +317,20 @@ class Reference:
     def _pp(arrs):
         return (_dp * 16)(*[_ptr(arrs[n]) for n in ARRAY_NAMES])
 
-    def compute_and_apply_rhs(self, arrs, Dvv, sc):
+    def compute_and_apply_rhs(self, arrs, Dvv, sc, reps=1):
+        """reps > 1: the reference driver's loop (main.cpp:113-121) inside ONE C call (no Python, no GIL between calls)."""
         ne = arrs["elem_state_dp3d"].shape[0]
         nete = ne if sc.get("nete") is None else sc["nete"]
         Dvv = np.ascontiguousarray(Dvv, dtype=np.float64)
         hyai = np.ascontiguousarray(sc["hyai"], dtype=np.float64)
         assert hyai.size == self.nlev + 1 and Dvv.size == self.np ** 2
-        self.lib.ref_compute_and_apply_rhs(self._pp(arrs), sc["nets"], nete, sc["n0"], sc["np1"],
-                                           sc["nm1"], sc["qn0"], sc["dt2"], sc["rrearth"],
-                                           sc["eta_ave_w"], sc["Rwater_vapor"], sc["Rgas"],
-                                           sc["kappa"], sc["ps0"], _ptr(hyai), _ptr(Dvv))
+        args = (self._pp(arrs), sc["nets"], nete, sc["n0"], sc["np1"], sc["nm1"], sc["qn0"], sc["dt2"], sc["rrearth"],
+                sc["eta_ave_w"], sc["Rwater_vapor"], sc["Rgas"], sc["kappa"], sc["ps0"], _ptr(hyai), _ptr(Dvv))
+        if reps != 1 and self.has_repeat:
+            self.lib.ref_compute_and_apply_rhs_repeat(*(args + (int(reps),)))
+            return
+        for _ in range(reps):
+            self.lib.ref_compute_and_apply_rhs(*args)
 
     def init_data(self, ne):
         arrs = alloc_arrays(self.np, self.nlev, self.qsize_d, self.timelevels, ne)

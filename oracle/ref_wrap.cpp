@@ -147,6 +147,17 @@ void ref_compute_and_apply_rhs(double* const arrays[16], int nets, int nete, int
   Homme::compute_and_apply_rhs(d);
 }
 
+// The reference driver's loop (main.cpp:113-121: `reps` back-to-back calls on the same TestData, the rotation commented
+// out) in one C call: bench.py's threaded CPU baseline runs it once per host thread, so no Python sits between the calls.
+void ref_compute_and_apply_rhs_repeat(double* const arrays[16], int nets, int nete, int n0, int np1, int nm1, int qn0,
+                                      double dt2, double rrearth, double eta_ave_w, double Rwater_vapor, double Rgas,
+                                      double kappa, double ps0, const double* hyai, const double* Dvv, int reps) {
+  Homme::TestData d;
+  bind_arrays(d.arrays, arrays);
+  fill_scalars(d, nets, nete, n0, np1, nm1, qn0, dt2, rrearth, eta_ave_w, Rwater_vapor, Rgas, kappa, ps0, hyai, Dvv);
+  for (int i = 0; i < reps; ++i) Homme::compute_and_apply_rhs(d);
+}
+
 // The three sphere operators (sphere_operators.cpp:9,50,91) for element `ie` of
 // caller-owned geometry arrays.  which: 0 gradient (in np*np, out np*np*2),
 // 1 divergence (in np*np*2, out np*np), 2 vorticity (in np*np*2, out np*np).

@@ -51,6 +51,7 @@ int main(int argc, char** argv) {
   TestData ref;
   ref.init_data();
   compute_and_apply_rhs(ref);
+  sync_to_host(ref);  // (resident mode, CAAR_SHIM_RESIDENT=1: the host arrays are stale until now; a no-op in mapped mode)
   const auto want = snapshot(ref, ne);
   ref.cleanup_data();
 
@@ -65,13 +66,15 @@ int main(int argc, char** argv) {
       compute_and_apply_rhs(mine);
     });
   for (auto& t : th) t.join();
+  sync_to_host(shared);
   const auto got = snapshot(shared, ne);
   for (int i = 0; i < 16; ++i)
     if (std::memcmp(got[i].data(), want[i].data(), sizeof(double) * want[i].size()) != 0) {
       std::printf("array %d differs between %d threads and one\n", i, nthreads);
       ++bad;
     }
-  std::printf("threads: %d element ranges on %d threads %s the single call\n", nthreads, nthreads, bad ? "DIFFER from" : "== bitwise");
+  std::printf("threads: %d element ranges on %d threads %s the single call (%s mode)\n", nthreads, nthreads,
+              bad ? "DIFFER from" : "== bitwise", shim_stats().resident ? "resident" : "mapped");
 
   // ---- (2) the operator functions -----------------------------------------------------------------
   const int pp = np * np;

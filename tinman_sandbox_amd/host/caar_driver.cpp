@@ -62,6 +62,8 @@ void usage() {
             << "|                              hybi(k) = (k/nlev)^2; default 1: Lagrangian |\n"
             << "|  --tinman-host-arrays=val  : arrays stay in host memory, as in the       |\n"
             << "|                              reference's loop (default=no: GPU-resident) |\n"
+            << "|  --tinman-resident=val     : with host arrays: the shim keeps a device   |\n"
+            << "|                              copy between calls (CAAR_SHIM_RESIDENT=1)   |\n"
             << "|  --tinman-help             : prints this message                         |\n"
             << "+--------------------------------------------------------------------------+\n";
 }
@@ -70,7 +72,7 @@ void usage() {
 
 int main(int argc, char** argv) {
   using namespace Homme;
-  bool dump_res = false, update_levels = false, host_arrays = false, use_graph = false;
+  bool dump_res = false, update_levels = false, host_arrays = false, use_graph = false, resident = false;
   int num_exec = 1, device = 0, num_devices = 1, rsplit = 1;
 
   for (int i = 1; i < argc; ++i) {
@@ -101,6 +103,9 @@ int main(int argc, char** argv) {
       if (!parse_yes_no(a, val, &use_graph)) return 1;
     } else if (starts_with(a, "--tinman-host-arrays=")) {
       if (!parse_yes_no(a, val, &host_arrays)) return 1;
+    } else if (starts_with(a, "--tinman-resident=")) {
+      if (!parse_yes_no(a, val, &resident)) return 1;
+      if (resident) host_arrays = true;
     } else if (starts_with(a, "--tinman-update-levels=")) {
       if (!parse_yes_no(a, val, &update_levels)) return 1;
     } else if (starts_with(a, "--tinman-help")) {
@@ -123,24 +128,26 @@ int main(int argc, char** argv) {
   print_results_2norm(data);
 
   if (host_arrays) {
-    // The reference's own loop (main.cpp:113-121): the arrays stay where TestData allocated
-    // them and every call goes through Homme::compute_and_apply_rhs(TestData&), i.e. over PCIe.
+    // The reference's own loop (main.cpp:113-121): the arrays stay where TestData allocated them and every call goes
+    // through Homme::compute_and_apply_rhs(TestData&) — over PCIe on the page-locked arrays (mapped mode), or, with
+    // --tinman-resident=yes (= CAAR_SHIM_RESIDENT=1), on a device copy the shim keeps between calls.
+    if (resident) setenv("CAAR_SHIM_RESIDENT", "1", 1);
     std::cout << " --- Performing computations on host-resident arrays... (" << num_exec
               << " executions of the main loop on " << num_elems << " elements)\n";
-    double first = 0, rest = 0;
+    const auto h0 = std::chrono::steady_clock::now();
     for (int i = 0; i < num_exec; ++i) {
-      const auto h0 = std::chrono::steady_clock::now();
       compute_and_apply_rhs(data);
-      const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count();
-      (i == 0 ? first : rest) += s;
       if (update_levels && i + 1 < num_exec) data.update_time_levels();
     }
-    std::cout << "   ---> compute_and_apply_rhs execution total time: " << first + rest << " s  (first call, which "
-              << "page-locks the arrays: " << first << " s";
-    if (num_exec > 1)
-      std::cout << "; then " << rest / (num_exec - 1) << " s per call = " << double(num_elems) * (num_exec - 1) / rest
-                << " element-updates/s including PCIe";
-    std::cout << "; kernel " << caar_kernel_name(np, nlev) << ")\n";
+    const ShimStats st = shim_stats();  // waits for the device
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count();
+    std::cout << "   ---> compute_and_apply_rhs execution total time: " << wall << " s  (" << (st.resident ? "resident" : "mapped")
+              << " mode; without the first call's " << (st.resident ? "upload" : "page-locking") << ": " << st.seconds << " s for "
+              << st.calls << " calls = " << 1e3 * st.seconds / double(st.calls) << " ms per call = "
+              << double(num_elems) * double(st.calls) / st.seconds << " element-updates/s"
+              << (st.resident ? "" : " including PCIe") << "; kernel " << caar_kernel_name(np, nlev) << ")\n";
+    std::cout << "shim_stats mode=" << (st.resident ? "resident" : "mapped") << " calls=" << st.calls << " seconds="
+              << std::setprecision(9) << st.seconds << " wall=" << wall << "\n";
     print_results_2norm(data);
     if (dump_res) dump_results_to_file(data);
     std::cout << " --- Cleaning up data...\n";

@@ -26,10 +26,29 @@ struct CaarPlacement;  // include/caar.h: where the device arrays are placed in 
 
 namespace Homme {
 
+// Two modes (homme_caar.cpp): mapped, the default — the kernel works on the host's page-locked arrays over PCIe and the
+// host may read them after every call; resident (environment CAAR_SHIM_RESIDENT=1, or -DCAAR_SHIM_RESIDENT) — the arrays
+// are uploaded on the first call and later calls only enqueue the kernel: the host's copies of the mutated arrays are
+// stale until sync_to_host(); print_results_2norm / dump_results_to_file / release_host_mapping know.
 void compute_and_apply_rhs(TestData& data);
-// Releases the page locks compute_and_apply_rhs(TestData&) holds on the host arrays it ran on last.  Call it
-// before freeing those arrays (not part of the reference's surface: its callee holds no state).
+// Releases what compute_and_apply_rhs(TestData&) holds on the host arrays it ran on last (page locks; in resident mode the
+// device copy, after writing its results back).  Call it before freeing those arrays (not part of the reference's
+// surface: its callee holds no state).
 void release_host_mapping();
+// Resident mode: bring the host arrays up to date (the seven arrays the path mutates) / send the host's arrays to the
+// device again after the host changed them.  No-ops in mapped mode and for arrays the shim holds no device copy of.
+// (cf. sync_to_host / sync_to_device of the reference's Kokkos variants, level_vectorized_ppscan/Utility.hpp)
+void sync_to_host(TestData& data);
+void sync_to_device(const TestData& data);
+// What the calls through compute_and_apply_rhs(TestData&) cost so far: `seconds` is wall time on the host from the first
+// enqueue after a wait to the completion of the last call (resident), or the sum of the calls' durations (mapped);
+// page-locking, the initial upload and downloads are not in it.  Waits for the device.
+struct ShimStats {
+  int resident;
+  long long calls;
+  double seconds;
+};
+ShimStats shim_stats();
 // compute_and_apply_rhs.hpp:11-17
 void preq_hydrostatic(const real* const phis, const real* const T_v, const real* const p, const real* dp, real Rgas,
                       real* const phi);
