@@ -1,6 +1,5 @@
 // caar_kernel_args.h — kernel argument block shared by the HIP kernels and the ABI layer.
-#ifndef CAAR_KERNEL_ARGS_H
-#define CAAR_KERNEL_ARGS_H
+#pragma once
 
 #include <hip/hip_runtime.h>
 
@@ -14,10 +13,6 @@
 // NLEV=128, whose two-workgroup shape spills 14 VGPRs and is still the fastest measured).
 #ifndef CAAR_EXTRA_NLEV
 #define CAAR_EXTRA_NLEV 0
-#endif
-
-#ifndef CAAR_CACHE_PICK_HASHED
-#define CAAR_CACHE_PICK_HASHED 0
 #endif
 
 namespace caar {
@@ -88,16 +83,8 @@ __device__ __forceinline__ long long element_of_block(const KernelArgs& k, unsig
 // launch that happens to process it: the budget is the device's, however the host cuts the range into launches.
 __device__ __forceinline__ bool element_is_cached(const KernelArgs& k, long long ie) {
   const unsigned long long c = (unsigned)k.cache_count, n = (unsigned)k.cache_n;
-#if CAAR_CACHE_PICK_HASHED   // experiment: a pseudo-random subset of the same density instead of every (n/c)-th element.
-  // The regular pick has a fine structure over the window size (+-0.5 %, single sizes up to 3 % off: aliasing of its period
-  // with how addresses map to memory channels), the hashed one is smooth; over six (NLEV, elements) cases and eight windows
-  // it is 0.7-1.7 % ahead in three cases, equal in two, 1.2 % behind at NLEV=128 / 12 500 elements — no clear winner, the
-  // regular pick stays (profiles/r04/window_fine_sweep_hashed.log against window_fine_sweep3.log, same box).
-  const unsigned h = ((unsigned)ie * 2654435761u) >> 12;          // 20 well-mixed bits
-  return c != 0 && (unsigned long long)(h & 0xFFFFFu) * n < c * 0x100000ull;
-#else
+  // (a hashed, pseudo-random pick of the same density was measured and is no better: docs/EXPERIMENTS.md A)
   return c != 0 && ((unsigned long long)(ie + 1) * c) / n > ((unsigned long long)ie * c) / n;
-#endif
 }
 
 // 1/x for a normal, non-zero fp64 x: v_rcp_f64 seed + two Newton steps (5 instructions,
@@ -230,4 +217,3 @@ struct EulerArgs {
 };
 
 }  // namespace caar
-#endif

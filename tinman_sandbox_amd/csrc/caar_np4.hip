@@ -7,14 +7,12 @@
 //
 // Mapping:
 //   * one workgroup = one element; one wavefront = TPW "tiles"; one tile = 4
-//     consecutive levels x 16 GLL points = 64 lanes (lane = 16a + 4lev + b, the operand layout of v_mfma_f64_4x4x4;
-//     lane = 16lev + 4a + b in the DPP build, -DCAAR_NP4_MFMA=0).
+//     consecutive levels x 16 GLL points = 64 lanes (lane = 16a + 4lev + b, the operand layout of v_mfma_f64_4x4x4).
 //     In the reference layout [lev][a][b] that is 64 consecutive doubles, so every
 //     field access of a wave covers one contiguous 512 B (scalar) / 1 KiB (v)
 //     segment and each input byte is read exactly once, each output written once.
-//   * the NP x NP Dvv contractions of a tile's four levels are ONE v_mfma_f64_4x4x4 each (caar_np4_ops.h "MFMA form";
-//     the DPP build keeps them inside the 16-lane DPP row of a level: d/da three row_ror moves, d/db four quad_perm
-//     broadcasts).  No cross-wave dependency either way.
+//   * the NP x NP Dvv contractions of a tile's four levels are ONE v_mfma_f64_4x4x4 each (caar_np4_ops.h "MFMA form").
+//     No cross-wave dependency.
 //   * Dvv and the element's metric terms (D, Dinv, metdet, rmetdet, fcor, spheremp,
 //     phis) are staged once per workgroup in LDS.
 //   * the three vertical integrals (pressure, geopotential, omega) are blocked

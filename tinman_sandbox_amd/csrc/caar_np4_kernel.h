@@ -1,8 +1,7 @@
 // caar_np4_kernel.h — the NP=4 kernel templates (element body, single-call kernel) shared by caar_np4.hip (launch
 // shapes and variant tables) and caar_np4_steps.hip (the step-loop kernel of caar_run_steps).  See caar_np4.hip for the
 // mapping.
-#ifndef CAAR_NP4_KERNEL_H
-#define CAAR_NP4_KERNEL_H
+#pragma once
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -16,37 +15,20 @@ namespace caar {
 // Lanes l, l+16, l+32, l+48 hold levels 4t..4t+3 of one GLL point.
 __device__ __forceinline__ double shfl_abs(double x, int src_lane) { return __shfl(x, src_lane, 64); }
 
-// Lane -> (level inside the tile, GLL point).  CAAR_NP4_MFMA = 1 (default): lane = 16a + 4lev + b, the operand / result
-// layout of v_mfma_f64_4x4x4 (caar_np4_ops.h "MFMA form"): the contractions of the four levels of a tile are ONE matrix
-// instruction each.  0: lane = 16lev + 4a + b, the Dvv contractions inside DPP rows (the form of rounds 1-3).  Either way a
-// wave covers the same 64 consecutive doubles of a field block; LSTEP is the lane distance between consecutive levels (the
-// in-tile scans).  The whole NP=4 family uses ONE form, so that every kernel of it — launch shapes, cache policies, the
-// step loops — stays bit-identical to every other.
-// Measured A/B, two builds alternating on one box.  With the 3 x 6 workgroups of rounds 2-3 the MFMA form made the step
-// loop 12 % faster but the memory-bound single call 0.5-1 % SLOWER (lanes of a wave address their 512 bytes in 32-byte
-// groups instead of in order; profiles/r03/kbench_mfma_vs_dpp.log), and the DPP form stayed.  With the four-wave workgroups
-// (one wave on every SIMD) it is ahead everywhere: headline 85.2-85.4 against 84.4-84.9 %, all-streaming 76.0-76.2 against
-// 75.5-75.7, step loop 0.123 against 0.131 ms per call (NLEV=128: 0.296 against 0.319), the Eulerian form of NLEV=128 +1
-// point, the run-time-level-count kernel 84.8 against 61.6 % at 20 levels, 57-65 against 38-50 % above 128 (its masked
-// form is short of registers and the MFMA form needs ~14 fewer); profiles/r03/kbench_mfma_vs_dpp_4w.log,
-// steps_bench_mfma_vs_dpp_4w.log, mfma_vs_dpp_other.log.  All GPU tests pass with either.
-#ifndef CAAR_NP4_MFMA
-#define CAAR_NP4_MFMA 1
-#endif
-constexpr bool kNp4Mfma = CAAR_NP4_MFMA != 0;
-constexpr int LSTEP = kNp4Mfma ? 4 : 16;
-using Np4Ctx = std::conditional<kNp4Mfma, Mfma4Ctx, RowCoef>::type;
+// Lane -> (level inside the tile, GLL point): lane = 16a + 4lev + b, the operand / result layout of v_mfma_f64_4x4x4
+// (caar_np4_ops.h "MFMA form"): the contractions of the four levels of a tile are ONE matrix instruction each.  A wave covers
+// 64 consecutive doubles of a field block; LSTEP is the lane distance between consecutive levels (the in-tile scans).  The
+// whole NP=4 family uses this ONE form, so that every kernel of it — launch shapes, cache policies, the step loops — stays
+// bit-identical to every other.  (Rounds 1-3 had lane = 16lev + 4a + b with the contractions inside DPP rows; the A/B that
+// retired it: docs/EXPERIMENTS.md A, CAAR_NP4_MFMA.)
+constexpr int LSTEP = 4;
+using Np4Ctx = Mfma4Ctx;
 
-// In the MFMA lane mapping (LSTEP = 4) the scan partners lane -/+ 4, -/+ 8 sit in the lane's own 16-lane row, so the moves
-// are DPP row shifts (row_shr / row_shl: v_mov_b32_dpp, two per fp64 value, no LDS traffic, no lgkmcnt wait) instead of
-// ds_bpermute pairs (CAAR_NP4_SCAN_DPP = 1, default; 0 = the __shfl form of rounds 1-3 for an A/B).  Pure data movement:
+// The scan partners lane -/+ 4, -/+ 8 sit in the lane's own 16-lane row, so the moves are DPP row shifts (row_shr / row_shl:
+// v_mov_b32_dpp, two per fp64 value, no LDS traffic, no lgkmcnt wait) instead of ds_bpermute pairs.  Pure data movement:
 // results are bit-identical to the __shfl form.  A lane without a partner (the row shift runs off the row) must add
 // NOTHING: its addend is -0.0 — x + (-0.0) == x for every x, signed zeros included, which x + 0.0 is not — built from the
 // halves: the low word with bound_ctrl (0 where there is no source lane), the high word keeps `old` = 0x80000000.
-#ifndef CAAR_NP4_SCAN_DPP
-#define CAAR_NP4_SCAN_DPP 1
-#endif
-constexpr bool kScanDpp = kNp4Mfma && CAAR_NP4_SCAN_DPP != 0;
 // Which kernels take the DPP form — measured, two builds alternating on one box (profiles/r04/dppscan_kbench.log,
 // dppscan_steps.log; 405 bit fingerprints of tools/ab_bits.py agree between the builds): NLEV=72 single call 83.6-84.3 ->
 // 86.0-87.3 % of peak (all-streaming 75-75.7 -> 76.4-78.2), step loops 0.1236 -> 0.1049 ms per call at NLEV=72 and
@@ -54,7 +36,7 @@ constexpr bool kScanDpp = kNp4Mfma && CAAR_NP4_SCAN_DPP != 0;
 // latency chain of a tile).  The single call at NLEV=128 did not gain (81.2 -> 80.9 %, its all-streaming twin 76.8 -> 75.6):
 // it keeps the __shfl form.
 template <int NLEV_T, bool STEPS>
-constexpr bool np4_scan_dpp() { return kScanDpp && !(NLEV_T == 128 && !STEPS); }
+constexpr bool np4_scan_dpp() { return !(NLEV_T == 128 && !STEPS); }
 enum { DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110 };
 // x of the lane CTRL names, or (lanes without a source) -0.0 if NEG_ZERO else +0.0
 template <int CTRL, bool NEG_ZERO>
@@ -246,12 +228,12 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pt = kNp4Mfma ? mfma4_point(lane) : lane & 15;
-  const int sub = kNp4Mfma ? mfma4_level(lane) : lane >> 4;
+  const int pt = mfma4_point(lane);
+  const int sub = mfma4_level(lane);
   const size_t tl = (size_t)k.timelevels;
   // RAGGED (NLEV not a multiple of 4): the rows of the last tile beyond level NLEV-1 are dead:
   // their loads are masked and return 0, they contribute 0 to the three integrals, and they
-  // store nothing.  A level is one block of the 4x4x4 MFMA (one DPP row in the DPP build), so dead rows never feed live ones.
+  // store nothing.  A level is one block of the 4x4x4 MFMA, so dead rows never feed live ones.
   const int tile0 = UNEVEN ? w * (TPW - 1) + (w < FULL ? w : FULL) : w * TPW;  // this wave's first tile (wave-uniform)
   const bool last_live = !UNEVEN || w < FULL;                                    // ... and whether it owns TPW tiles
   const int ntile = last_live ? TPW : TPW - 1;
@@ -267,7 +249,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   // wave's first tile folded in: an SGPR pair) and is indexed by `r * 64 + ulane` with r
   // a compile-time tile number and ulane an UNSIGNED lane id, so each access is one
   // global_load/store with scalar base, one shared 32-bit lane offset and an immediate.
-  const unsigned ulane = kNp4Mfma ? sub * 16 + pt : lane;  // this lane's offset inside a tile of the layout [lev][a][b]
+  const unsigned ulane = sub * 16 + pt;  // this lane's offset inside a tile of the layout [lev][a][b]
   // (the even shapes keep the expression they always had: the headline kernels' code must not change with this option)
   const size_t wbase = UNEVEN ? (size_t)tile0 * 64 : (size_t)w * (TPW * 64);  // first point of this wave's tiles inside a field block
 
@@ -445,7 +427,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     if (!(carry_flags & 1)) wg_barrier<PERSIST || STEPS>();  // also fences the previous element's last reads of the tile totals
 
     if (first) {
-      make_np4_ctx(c, s_dvv, lane);
+      c = make_mfma4_ctx(s_dvv, lane);
       first = false;
     }
     M22 Dinv;
@@ -529,7 +511,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     }
     TileIn cur = PF ? pre[TPW - 1] : load_tile(TPW - 1);  // in flight across the barrier
     double l_eta_last = 0.0;
-    if (tid < PP && eta_rmw) l_eta_last = eta_last[kNp4Mfma ? (unsigned)tid : ulane];
+    if (tid < PP && eta_rmw) l_eta_last = eta_last[(unsigned)tid];
     wg_barrier<PERSIST || STEPS>();
 
     // PERSIST: request the next element's n0 inputs now; they land while phase 3 computes
@@ -719,7 +701,7 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
     }
     if (tid < PP && eta_rmw) {
       const double e_new = l_eta_last + eta_zero;                     // P:181
-      if (!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(l_eta_last)) eta_last[kNp4Mfma ? (unsigned)tid : ulane] = e_new;
+      if (!ETA_COND || __double_as_longlong(e_new) != __double_as_longlong(l_eta_last)) eta_last[(unsigned)tid] = e_new;
     }
 
     if (!PERSIST || nxt_ie < 0) break;
@@ -761,4 +743,3 @@ __global__ __launch_bounds__(NLEV_T ? ((NLEV_T + 3) / 4 + TPW - 1) / TPW * 64 : 
 }
 
 }  // namespace caar
-#endif

@@ -3,11 +3,10 @@
 // gradient_sphere / divergence_sphere / vorticity_sphere of the reference
 // (compute_and_apply_rhs_test/cxx/pointers_only/sphere_operators.cpp:9-129, cited as S:):
 //   * DPP form: lane = a*4 + b of a 16-lane row holding one level of one element (the simple stand-alone operators,
-//     caar_operators.hip / caar_operators_ex.hip; the fused kernels in the -DCAAR_NP4_MFMA=0 build);
+//     caar_operators.hip / caar_operators_ex.hip);
 //   * MFMA form (second half of this file): the four levels of a tile through one v_mfma_f64_4x4x4 per contraction —
 //     the fused kernels (caar_np4_kernel.h, default) and the composite operators.
-#ifndef CAAR_NP4_OPS_H
-#define CAAR_NP4_OPS_H
+#pragma once
 
 #include <hip/hip_runtime.h>
 
@@ -95,7 +94,7 @@ __device__ __forceinline__ RowCoef make_row_coef(const double* dvv, int lane) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// MFMA form of the NP=4 contractions: what the fused kernels use by default (caar_np4_kernel.h CAAR_NP4_MFMA) and what
+// MFMA form of the NP=4 contractions: what the fused kernels use (caar_np4_kernel.h) and what
 // the composite operators of caar_operators_ex.hip need (2-6 contraction pairs per point for 1-2 KiB of traffic per tile:
 // bound by VALU issue in the DPP form, which costs 14 cross-lane moves + 8 FMAs per pair).  v_mfma_f64_4x4x4_4b_f64 multiplies four independent 4x4 blocks per
 // issue: one block = one LEVEL of the tile, so one issue is one contraction of all four levels a wave holds.
@@ -109,78 +108,30 @@ __device__ __forceinline__ RowCoef make_row_coef(const double* dvv, int lane) {
 //   wa, wb            : the same with the constants taken from Dvv^T.
 __device__ __forceinline__ int mfma4_point(int lane) { return (lane >> 4) * 4 + (lane & 3); }  // a*4 + b
 __device__ __forceinline__ int mfma4_level(int lane) { return (lane >> 2) & 3; }               // level inside the tile
-// CAAR_NP4_DB_DPP = 1 (experiment; default 0): d/db — the contraction over the index that lies inside a lane quad in this
-// mapping — as four quad_perm broadcasts + an FMA chain instead of ds_bpermute + MFMA: no LDS round trip, 11 more VALU
-// instructions per contraction, four more per-lane constants.  Bit-identical to the MFMA form on all 405 fingerprints of
-// tools/ab_bits.py (v_mfma_f64_4x4x4 IS the k-ascending fma chain), and no faster: headline 87.0-87.4 against 87.0-87.5 %,
-// step loop 0.1055 against 0.1048 ms per call (profiles/r04/dbdpp_kbench.log, dbdpp_steps.log).  Not adopted.
-#ifndef CAAR_NP4_DB_DPP
-#define CAAR_NP4_DB_DPP 0
-#endif
-#ifndef CAAR_NP4_DB_SPREAD
-#define CAAR_NP4_DB_SPREAD 0
-#endif
 struct Mfma4Ctx {
   double d_hl;  // Dvv[h][l] for lane = 16h + 4blk + l: A operand of da, B operand of db
   double d_lh;  // Dvv[l][h]: A operand of wa, B operand of wb
   int src_t;    // the lane that holds F[l][h] of this lane's level: 16l + 4blk + h
-#if CAAR_NP4_DB_DPP
-  double cb[4];  // Dvv[k][l]
-#endif
 };
 __device__ __forceinline__ Mfma4Ctx make_mfma4_ctx(const double* dvv /* Dvv[k][j] row-major */, int lane) {
   const int h = lane >> 4, blk = (lane >> 2) & 3, l = lane & 3;
   Mfma4Ctx c;
   c.d_hl = dvv[h * 4 + l];
   c.d_lh = dvv[l * 4 + h];
-#if CAAR_NP4_DB_SPREAD
-  c.src_t = 16 * l + 4 * blk + (l >= 2 ? (h ^ 2) : h);
-#else
   c.src_t = 16 * l + 4 * blk + h;
-#endif
-#if CAAR_NP4_DB_DPP
-  for (int k = 0; k < 4; ++k) c.cb[k] = dvv[k * 4 + l];
-#endif
   return c;
 }
 __device__ __forceinline__ double mfma4x4(double a, double b) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, 0.0, 0, 0, 0); }
 // sum_k Dvv[k][a] f[k][b]
 __device__ __forceinline__ double mfma4_d_da(const Mfma4Ctx& c, double f) { return mfma4x4(c.d_hl, f); }
 // sum_k Dvv[k][b] f[a][k]
-#if CAAR_NP4_DB_DPP
-__device__ __forceinline__ double mfma4_d_db(const Mfma4Ctx& c, double f) {
-  double s = c.cb[0] * dpp<0x00>(f);
-  s = __builtin_fma(c.cb[1], dpp<0x55>(f), s);
-  s = __builtin_fma(c.cb[2], dpp<0xAA>(f), s);
-  return __builtin_fma(c.cb[3], dpp<0xFF>(f), s);
-}
-#elif CAAR_NP4_DB_SPREAD
-// (experiment, -DCAAR_NP4_DB_SPREAD=1) rows 2, 3 swap the lane pairs of every quad first (quad_perm [2,3,0,1], row_mask 0xC), so
-// that the 32 lanes of a ds_bpermute group fetch from lanes on 32 different banks (as it stands rows l and l + 2 collide: 2
-// extra LDS cycles each, the 360 SQ_LDS_BANK_CONFLICT cycles per element-call that are left at NLEV=72).  Bit-identical, and
-// not adopted: single call equal (86.3-87.2 against 86.6-87.5 %), step loop 0.1084 against 0.1044 ms per call — the extra move
-// sits in front of the transpose in a dependent chain, and the conflict cycles it removes were not on anybody's critical path
-// (profiles/r04/spread4_*.log; the same finding as for NP=8, caar_np8_ops.h).
-__device__ __forceinline__ double mfma4_d_db(const Mfma4Ctx& c, double f) {
-  f = __builtin_amdgcn_update_dpp(f, f, 0x4E, 0xC, 0xf, false);
-  return mfma4x4(__shfl(f, c.src_t, 64), c.d_hl);
-}
-#else
+// (one 64-bit ds_bpermute moves F into the transposed in-block placement; the DPP / bank-spread alternatives: docs/EXPERIMENTS.md A)
 __device__ __forceinline__ double mfma4_d_db(const Mfma4Ctx& c, double f) { return mfma4x4(__shfl(f, c.src_t, 64), c.d_hl); }
-#endif
 // sum_k Dvv[a][k] f[k][b]
 __device__ __forceinline__ double mfma4_w_a(const Mfma4Ctx& c, double f) { return mfma4x4(c.d_lh, f); }
 // sum_k Dvv[b][k] f[a][k]
-__device__ __forceinline__ double mfma4_w_b(const Mfma4Ctx& c, double f) {
-#if CAAR_NP4_DB_SPREAD
-  f = __builtin_amdgcn_update_dpp(f, f, 0x4E, 0xC, 0xf, false);
-#endif
-  return mfma4x4(__shfl(f, c.src_t, 64), c.d_lh);
-}
+__device__ __forceinline__ double mfma4_w_b(const Mfma4Ctx& c, double f) { return mfma4x4(__shfl(f, c.src_t, 64), c.d_lh); }
 
-// one name for both forms' coefficient set-up (the kernels pick the form at compile time)
-__device__ __forceinline__ void make_np4_ctx(RowCoef& c, const double* dvv, int lane) { c = make_row_coef(dvv, lane); }
-__device__ __forceinline__ void make_np4_ctx(Mfma4Ctx& c, const double* dvv, int lane) { c = make_mfma4_ctx(dvv, lane); }
 
 // the three operators of the path (S:9-129) on the MFMA contractions: the same formulas as the DPP forms above
 __device__ __forceinline__ void gradient_sphere(const Mfma4Ctx& c, const M22& Dinv, double rrearth, double s, double& g0, double& g1) {
@@ -202,4 +153,3 @@ __device__ __forceinline__ double vorticity_sphere(const Mfma4Ctx& c, const M22&
 }
 
 }  // namespace caar
-#endif

@@ -107,16 +107,14 @@ static hipError_t launch_np4_steps(const KernelArgs& k, int num_elems, int nstep
 // What the NLEV=72 two-workgroup loop carries in LDS from call to call.  4 (default since round 4): the nm1 state AND the
 // accumulators vn0, omega_p — 7 slots, 80.2 KB per workgroup, the most that still lets two workgroups share a CU; a steady
 // call then reads only the tracer block and pecnd (18 KB per element instead of 64 KB read + written) and writes nothing.
-// 1 (rounds 3-4a): the nm1 state and the tracer block, the accumulators through the L2 / Infinity Cache.  Same speed with
+// (Rounds 3-4a carried 1: the nm1 state and the tracer block, the accumulators through the L2 / Infinity Cache.)  Same speed with
 // the default cache policy (0.1046 against 0.1050 ms per call at 10 000 elements: the loop is bound by instruction issue and
 // latency at two waves per SIMD, not by memory) — but no longer dependent on it (the all-streaming loop: 0.1218 -> 0.1053) or
 // on what else uses the caches; bit-identical (profiles/r04/carry4_steps.log, carry4_bits.log).
-#ifndef CAAR_STEPS72_CARRY
-#define CAAR_STEPS72_CARRY 4
-#endif
+constexpr int kSteps72Carry = 4;
 #define CAAR_STEPS(NLEV, TPW, MINW, POL, PF, PARK)                                                                  \
   hipError_t launch_np4_steps_##NLEV##_##POL(const KernelArgs& k, int num_elems, int nsteps, int rotate, hipStream_t s) { \
-    return launch_np4_steps<NLEV, TPW, MINW, POL, PF, PARK, (NLEV == 72 ? CAAR_STEPS72_CARRY : (NLEV <= 80 ? 1 : 0))>(k, num_elems, nsteps, rotate, s); \
+    return launch_np4_steps<NLEV, TPW, MINW, POL, PF, PARK, (NLEV == 72 ? kSteps72Carry : (NLEV <= 80 ? 1 : 0))>(k, num_elems, nsteps, rotate, s); \
   }
 // NLEV=72: FOUR waves with 5, 5, 4, 4 of the 18 tiles (caar_np4_kernel.h UNEVEN), two workgroups per CU: the loop is bound by
 // instruction issue, and two 3 x 6 workgroups put 2, 2, 1, 1 waves on a CU's four SIMDs (12 tiles per pair of elements on

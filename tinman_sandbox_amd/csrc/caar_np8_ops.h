@@ -2,8 +2,7 @@
 // contractions: the DEFAULT "MFMA form" (v_mfma_f64_4x4x4, lane = MFMA result layout, no LDS tile; further down) and
 // the direct form through a wave-private 64-double LDS tile (the comparator variant; first in this file).
 // Reference: cxx/pointers_only/sphere_operators.cpp:9-129 (S:).
-#ifndef CAAR_NP8_OPS_H
-#define CAAR_NP8_OPS_H
+#pragma once
 
 #include <hip/hip_runtime.h>
 
@@ -158,24 +157,10 @@ __device__ __forceinline__ int mfma_lane_of_point(int p) {
   return 16 * (a & 3) + 8 * (a >> 2) + b;
 }
 
-// CAAR_NP8_DB_SPREAD = 1 (experiment; default 0): the d/db transpose reads lanes whose ds_bpermute banks (source lane mod
-// 32) are all different.  As the layout stands the 32 lanes of a bpermute group fetch F[4I + l][4K + h] from lane
-// 16l + 8I + 4K + h: rows l and l + 2 collide on every bank (2 extra LDS cycles per ds_bpermute_b32, 2 880 of the 6 468
-// conflict cycles per element-call in profiles/r03/pmc_issue.json).  One DPP row_half_mirror confined to rows 2 and 3
-// (row_mask 0xC: position p of an 8-lane half -> 7 - p, i.e. k-block K <-> 1 - K) first moves their values to the other
-// quad of the half, and src_db points there: conflict-free, pure data movement (bit-identical, tools/ab_bits.py).
-// Measured and NOT adopted: the two extra VALU moves per transpose cost more than the conflict cycles they remove — the
-// NP=8 step loop goes from 1.010 to 1.046 ms per call at 20 000 elements, the single call is unchanged
-// (profiles/r04/np8lds_steps.log, np8lds_kbench.log): these kernels are short of VALU issue slots, not of LDS cycles.
-#ifndef CAAR_NP8_DB_SPREAD
-#define CAAR_NP8_DB_SPREAD 0
-#endif
-constexpr bool kDbSpread = CAAR_NP8_DB_SPREAD != 0;
-
 struct MfmaCtx {
   double a_da[2];  // A operand of d/da for k-block K: Dvv[4K + h][4I + l]     (lane = 16h + 8I + 4J + l)
   double b_db[2];  // B operand of d/db for k-block K: Dvv[4K + h][4J + l]
-  int src_db[2];   // lane that holds F[4I + l][4K + h]: 16l + 8I + 4K + h (kDbSpread: rows l >= 2 half-mirrored)
+  int src_db[2];   // lane that holds F[4I + l][4K + h]: 16l + 8I + 4K + h
 };
 
 __device__ __forceinline__ MfmaCtx make_mfma_ctx(const double* dvv /* Dvv[k][j] row-major, any address space */, int lane) {
@@ -185,45 +170,28 @@ __device__ __forceinline__ MfmaCtx make_mfma_ctx(const double* dvv /* Dvv[k][j] 
   for (int K = 0; K < 2; ++K) {
     c.a_da[K] = dvv[(4 * K + h) * NP + 4 * I + l];
     c.b_db[K] = dvv[(4 * K + h) * NP + 4 * J + l];
-    c.src_db[K] = (kDbSpread && l >= 2) ? 16 * l + 8 * I + 7 - (4 * K + h) : 16 * l + 8 * I + 4 * K + h;
+    c.src_db[K] = 16 * l + 8 * I + 4 * K + h;
   }
   return c;
-}
-
-// DPP move whose result is taken only by the lanes of the enabled 4-lane banks of each 16-lane row; the
-// others keep x (dpp_ctrl 0x128 = row_ror:8: the value 8 lanes away in the row).
-template <int BANK_MASK>
-__device__ __forceinline__ double swap8_banked(double x) {
-  return __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, BANK_MASK, false);
 }
 
 __device__ __forceinline__ double mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
-// CAAR_NP8_DA_SELECT = 1 (default since round 4): the two B operands of d/da from ONE unmasked row_ror:8 (the value 8 lanes
-// away in the row, for every lane: two v_mov_b32_dpp into a fresh register) and two selects by the lane's half of the row
-// (v_cndmask with a constant lane mask) — 6 VALU instructions.  0: two bank-masked DPP moves (rounds 2-3), each of which
-// first copies the field (the masked lanes keep `old`): 8.  Pure data movement, bit-identical.
-#ifndef CAAR_NP8_DA_SELECT
-#define CAAR_NP8_DA_SELECT 1
-#endif
+// The two B operands of d/da come from ONE unmasked row_ror:8 (the value 8 lanes away in the row, for every lane: two
+// v_mov_b32_dpp into a fresh register) and two selects by the lane's half of the row (v_cndmask with a constant lane mask):
+// 6 VALU instructions, pure data movement.  (Rounds 2-3 used two bank-masked DPP moves, 8: docs/EXPERIMENTS.md A.)
 // sum_k Dvv[k][a] f[k][b] at this lane's point (a, b)
 __device__ __forceinline__ double mfma_d_da(const MfmaCtx& c, double f) {
-#if CAAR_NP8_DA_SELECT
   const double p = __builtin_amdgcn_update_dpp(0.0, f, 0x128, 0xf, 0xf, true);  // row_ror:8, every lane has a source
   const bool upper = (__lane_id() & 8) != 0;                                    // I = 1: lanes 8..15 of each row
   const double b0 = upper ? p : f;  // block row K = 0: lanes 8..15 take lane - 8's value
   const double b1 = upper ? f : p;  // block row K = 1: lanes 0..7 take lane + 8's value
-#else
-  const double b0 = swap8_banked<0xC>(f);  // block row K = 0: lanes 8..15 of each row take lane - 8's value
-  const double b1 = swap8_banked<0x3>(f);  // block row K = 1: lanes 0..7 take lane + 8's value
-#endif
   return mfma4(c.a_da[1], b1, mfma4(c.a_da[0], b0, 0.0));
 }
 // sum_k Dvv[k][b] f[a][k]
 __device__ __forceinline__ double mfma_d_db(const MfmaCtx& c, double f) {
-  if constexpr (kDbSpread) f = __builtin_amdgcn_update_dpp(f, f, 0x141 /* row_half_mirror */, 0xC /* rows 2, 3 */, 0xf, false);
   const double a0 = __shfl(f, c.src_db[0], 64);
   const double a1 = __shfl(f, c.src_db[1], 64);
   return mfma4(a1, c.b_db[1], mfma4(a0, c.b_db[0], 0.0));
@@ -253,4 +221,3 @@ __device__ __forceinline__ double vorticity_sphere_mfma(const MfmaCtx& c, const 
 }  // namespace np8
 
 }  // namespace caar
-#endif
