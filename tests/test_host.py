@@ -22,17 +22,49 @@ def lib():
     return tsa.library()
 
 
-def test_library_exports_every_declared_symbol(lib):
-    """Every function include/caar.h declares is exported by libcaar_hip.so."""
-    hdr = open(os.path.join(ROOT, "include", "caar.h")).read()
+def _declared(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(caar_[a-z_0-9]+)\s*\(", hdr))
-    assert declared, "no declarations parsed"
-    assert declared == set(m.CaarLibrary.SYMBOLS)
-    for s in declared:
+    return set(re.findall(r"\b(caar_[a-z_0-9]+)\s*\(", hdr))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    """Every function include/caar.h (the frozen boundary) and include/caar_tuning.h declare is exported by libcaar_hip.so,
+    the two headers are disjoint, and the Python binding lists exactly the same two sets."""
+    boundary, tuning = _declared("caar.h"), _declared("caar_tuning.h")
+    assert boundary and tuning, "no declarations parsed"
+    assert not (boundary & tuning)
+    assert boundary == set(m.CaarLibrary.BOUNDARY_SYMBOLS)
+    assert tuning == set(m.CaarLibrary.TUNING_SYMBOLS)
+    for s in boundary | tuning:
         assert hasattr(lib.lib, s), s
     import __graft_entry__ as entry
-    assert lib.lib.caar_abi_version() == entry.header_abi_version()
+    assert lib.lib.caar_abi_version() == entry.header_abi_version() == 6
+
+
+def test_boundary_is_what_integration_md_lists_and_what_the_hosts_bind():
+    """include/caar.h is frozen at ABI 6.  Its exported-symbol set equals the list in INTEGRATION.md
+    section 3 ("The frozen boundary"), and the host bindings use nothing outside it: the undefined caar_* symbols of
+    host/libhomme_caar.so (the C++ shim the reference's main.cpp links) and the bind(C) names of host/fortran/caar_mod.F90
+    are subsets of it."""
+    import subprocess
+    boundary = _declared("caar.h")
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("### The frozen boundary"):]
+    sec = sec[:sec.index("\n## ")] if "\n## " in sec else sec
+    listed = set(re.findall(r"`(caar_[a-z_0-9]+)`", sec[:sec.index("### Tuning")]))
+    assert listed == boundary, (sorted(listed - boundary), sorted(boundary - listed))
+    tbuild.build_host_driver()
+    shim = os.path.join(ROOT, "tinman_sandbox_amd", "host", "libhomme_caar.so")
+    nm = subprocess.run(["nm", "-D", "--undefined-only", shim], check=True, capture_output=True, text=True).stdout
+    used = set(re.findall(r"\bU (caar_[a-z_0-9]+)", nm))
+    assert used and used <= boundary, sorted(used - boundary)
+    f90 = open(os.path.join(ROOT, "tinman_sandbox_amd", "host", "fortran", "caar_mod.F90")).read()
+    bound = set(re.findall(r'bind\(C,\s*name="(caar_[a-z_0-9]+)"\)', f90))
+    assert bound and bound <= boundary, sorted(bound - boundary)
+    # the shim's sources name only the boundary header
+    for f in ("homme_caar.cpp", "homme_caar.hpp"):
+        assert "caar_tuning.h" not in open(os.path.join(ROOT, "tinman_sandbox_amd", "host", f)).read(), f
 
 
 def test_graft_entry_build_succeeds_on_a_built_tree(capsys):
@@ -52,6 +84,16 @@ def test_supported_variants_and_names(lib):
     assert lib.lib.caar_supported(4, 27) == 1 and lib.lib.caar_supported(4, 256) == 1   # run-time level count
     assert lib.lib.caar_supported(4, 1) == 0 and lib.lib.caar_supported(4, 257) == 0
     assert lib.lib.caar_supported(8, 128) == 0
+    # per vertical form (ABI 6): the default library has no Eulerian form beyond 128 levels
+    for np_, nlev in ((4, 72), (4, 128), (4, 27), (8, 72)):
+        assert lib.lib.caar_supported_ex(np_, nlev, 1) == 1 and lib.lib.caar_supported_ex(np_, nlev, 0) == 1
+    assert lib.lib.caar_supported_ex(4, 129, 1) == 1 and lib.lib.caar_supported_ex(4, 256, 1) == 1
+    assert lib.lib.caar_supported_ex(4, 129, 0) == 0 and lib.lib.caar_supported_ex(4, 256, 0) == 0
+    assert lib.lib.caar_supported_ex(5, 72, 1) == 0 and lib.lib.caar_supported_ex(4, 72, -1) == 0
+    extra = os.path.join(ROOT, "tinman_sandbox_amd", "csrc", "libcaar_hip_extra.so")
+    if os.path.exists(extra):
+        X = C.CDLL(extra)
+        assert X.caar_supported_ex(4, 200, 0) == 1 and X.caar_abi_version() == 6
     assert b"caar" in lib.lib.caar_kernel_name(4, 72)
     assert lib.lib.caar_kernel_name(3, 3) is None
     assert lib.lib.caar_strerror(-2).decode().startswith("no kernel")
@@ -84,6 +126,11 @@ def test_launch_validates_without_touching_a_device(lib):
     fake = m._CaarArrays(*[C.cast(64, m._dp)] * 16)
     assert lib.lib.caar_launch(C.byref(dims2), C.byref(fake), C.c_void_p(64), C.byref(prm), None) == -2
     assert lib.lib.caar_launch(None, None, None, None, None) == -1
+    # rsplit == 0 beyond 128 levels: refused up front with CAAR_EUNSUPPORTED (no launch is attempted)
+    dims3 = m._CaarDims(4, 200, 1, 3, 4)
+    prm3 = m._CaarParams(0, 4, 0, 1, 2, 0, 1.0, 1.0, 1.0, 461.5, 287.04, 0.28, 10.0, 201.0, None, 0, None, C.cast(64, m._dp))
+    assert lib.lib.caar_launch(C.byref(dims3), C.byref(fake), C.c_void_p(64), C.byref(prm3), None) == -2
+    assert lib.lib.caar_launch_steps(C.byref(dims3), C.byref(fake), C.c_void_p(64), C.byref(prm3), 3, 1, None) == -2
 
 
 def test_missing_library_fails_loudly(tmp_path):
@@ -138,14 +185,17 @@ def test_shard_range_partitions_exactly():
 
 
 def test_header_is_plain_c_and_links_from_c(tmp_path, lib):
-    """include/caar.h must be usable from C (the ABI is a C ABI): compile a C99 translation
-    unit against it with gcc -Wall -Werror, link it to libcaar_hip.so and run the calls that
-    need no GPU."""
+    """include/caar.h and include/caar_tuning.h must be usable from C (the ABI is a C ABI): compile a C99 translation
+    unit against each with gcc -Wall -Werror (caar.h on its own first: the boundary must not need the tuning header),
+    link to libcaar_hip.so and run the calls that need no GPU."""
     import subprocess
     src = tmp_path / "abi_probe.c"
     src.write_text(r'''
 #include <stdio.h>
 #include "caar.h"
+#ifdef WITH_TUNING
+#include "caar_tuning.h"
+#endif
 int main(void) {
   CaarDims d = {4, 72, 1, 3, 10};
   CaarParams p = {0};
@@ -156,17 +206,23 @@ int main(void) {
   if (caar_algorithmic_bytes(4, 72, 0) != 213888) return 4;
   p.nete = 11; /* > num_elems: refused before any device is touched */
   if (caar_launch(&d, &a, 0, &p, 0) != CAAR_EINVAL) return 5;
-  printf("%s|%s\n", caar_kernel_name(4, 72), caar_strerror(CAAR_EUNSUPPORTED));
+  if (!caar_supported_ex(4, 128, 0) || caar_supported_ex(4, 129, 0)) return 6;
+#ifdef WITH_TUNING
+  if (caar_get_cache_window() != CAAR_CACHE_WINDOW_DEFAULT) return 7;
+  printf("%s|", caar_kernel_name(4, 72));
+#endif
+  printf("%s\n", caar_strerror(CAAR_EUNSUPPORTED));
   return 0;
 }
 ''')
     exe = tmp_path / "abi_probe"
     csrc = os.path.join(ROOT, "tinman_sandbox_amd", "csrc")
-    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                    str(src), "-L" + csrc, "-lcaar_hip", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib",
-                    "-o", str(exe)], check=True)
-    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
-    assert "caar_np4_kernel<72" in out and "no kernel" in out
+    for defs in ([], ["-DWITH_TUNING"]):
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include")] + defs +
+                       [str(src), "-L" + csrc, "-lcaar_hip", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib",
+                        "-o", str(exe)], check=True)
+        out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+        assert "no kernel" in out and (("caar_np4_kernel<72" in out) == bool(defs))
 
 
 def test_shipped_code_object_holds_what_design_says():

@@ -50,7 +50,7 @@ def build_library(force=False, verbose=False, jobs=4, debug=False, extra=False):
     counter, include/caar.h caar_debug_dp3d_violations); the other objects are the release ones."""
     from concurrent.futures import ThreadPoolExecutor
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
-        os.path.join(HERE, "..", "include", "caar.h")]
+        os.path.join(HERE, "..", "include", "caar.h"), os.path.join(HERE, "..", "include", "caar_tuning.h")]
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
@@ -85,7 +85,8 @@ def build_host_driver(force=False, verbose=False, np_=4, nlev=72):
     suffix = "" if (np_, nlev) == (4, 72) else "_np%d_nlev%d" % (np_, nlev)
     shim = os.path.join(HOST, "libhomme_caar%s.so" % suffix)
     exe = os.path.join(HOST, "caar_driver%s" % suffix)
-    hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")]
+    hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [
+        os.path.join(HERE, "..", "include", "caar.h"), os.path.join(HERE, "..", "include", "caar_tuning.h")]
     # $ORIGIN-relative run paths: the tree can be moved (the GPU box mounts it elsewhere)
     link = ["-L" + CSRC, "-lcaar_hip", "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath,/opt/rocm/lib"]
     shim_srcs = [os.path.join(HOST, "homme_caar.cpp"), os.path.join(HOST, "homme_data.cpp")]

@@ -19,8 +19,11 @@ import numpy as np
 import torch  # imported BEFORE the HIP library is loaded so both share one HIP runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# CAAR_LIBRARY=debug loads the -DCAAR_DEBUG build (dp3d(np1) > 0 checked by the kernels, caar_debug_dp3d_violations)
-LIB_PATH = os.path.join(_HERE, "csrc", {"debug": "libcaar_hip_debug.so"}.get(os.environ.get("CAAR_LIBRARY", ""), "libcaar_hip.so"))
+# CAAR_LIBRARY=debug loads the -DCAAR_DEBUG build (dp3d(np1) > 0 checked by the kernels, caar_debug_dp3d_violations);
+# CAAR_LIBRARY=extra the -DCAAR_EXTRA_NLEV=1 build (shapes specialised for seven more level counts, the Eulerian form
+# beyond 128 levels: include/caar.h caar_supported_ex)
+LIB_PATH = os.path.join(_HERE, "csrc", {"debug": "libcaar_hip_debug.so", "extra": "libcaar_hip_extra.so"}.get(
+    os.environ.get("CAAR_LIBRARY", ""), "libcaar_hip.so"))
 if os.environ.get("CAAR_LIBRARY_PATH"):  # an explicitly named build (A/B of compile-time choices)
     LIB_PATH = os.environ["CAAR_LIBRARY_PATH"]
 
@@ -95,14 +98,28 @@ SPHERE_OPERATORS = {
 
 
 class CaarLibrary:
-    """ctypes view of libcaar_hip.so; every symbol of include/caar.h is bound here."""
+    """ctypes view of libcaar_hip.so; every symbol of include/caar.h and include/caar_tuning.h is bound here."""
 
-    SYMBOLS = ("caar_supported", "caar_abi_version", "caar_debug_dp3d_violations", "caar_device_count", "caar_strerror", "caar_array_len",
-               "caar_algorithmic_bytes", "caar_launch", "caar_launch_steps", "caar_launch_state_norms", "caar_sphere_operator", "caar_sphere_operator_range", "caar_sphere_operator_ex", "caar_euler_step", "caar_preq_hydrostatic", "caar_preq_omega_ps", "caar_sphere_operator_host", "caar_preq_hydrostatic_host", "caar_preq_omega_ps_host", "caar_reciprocal",
-               "caar_kernel_name", "caar_num_variants", "caar_select_variant",
-               "caar_variant_info", "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_context_cache_window", "caar_set_adaptive_window", "caar_get_adaptive_window", "caar_adaptive_window_state", "caar_adaptive_window_reset", "caar_selected_variant", "caar_layout_from_f90", "caar_layout_to_f90", "caar_stream_copy", "caar_stream_copy_tuned", "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_arrays_alloc", "caar_arrays_alloc_ex", "caar_arrays_free", "caar_arrays_placement", "caar_create", "caar_create_ex", "caar_destroy", "caar_upload", "caar_download", "caar_upload_f90", "caar_upload_f90_arrays", "caar_download_f90",
-               "caar_run", "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms",
-               "caar_time_runs", "caar_run_steps", "caar_set_fused_steps", "caar_get_fused_steps", "caar_has_fused_steps", "caar_map_host", "caar_run_mapped", "caar_unmap_host")
+    # the frozen boundary, include/caar.h (ABI 6) — tests/test_host.py holds this list against the header and INTEGRATION.md
+    BOUNDARY_SYMBOLS = (
+        "caar_supported", "caar_supported_ex", "caar_abi_version", "caar_device_count", "caar_strerror", "caar_array_len",
+        "caar_algorithmic_bytes", "caar_launch", "caar_launch_steps", "caar_sphere_operator", "caar_sphere_operator_range",
+        "caar_sphere_operator_ex", "caar_euler_step", "caar_preq_hydrostatic", "caar_preq_omega_ps", "caar_sphere_operator_host",
+        "caar_preq_hydrostatic_host", "caar_preq_omega_ps_host", "caar_launch_state_norms", "caar_layout_from_f90",
+        "caar_layout_to_f90", "caar_arrays_alloc", "caar_arrays_free", "caar_create", "caar_destroy", "caar_upload",
+        "caar_download", "caar_upload_f90", "caar_download_f90", "caar_upload_f90_arrays", "caar_run", "caar_run_steps",
+        "caar_sync", "caar_device_arrays", "caar_stream", "caar_state_norms", "caar_map_host", "caar_run_mapped",
+        "caar_unmap_host")
+    # include/caar_tuning.h: variants, cache policy, placement, measurement, debug — not part of the boundary
+    TUNING_SYMBOLS = (
+        "caar_kernel_name", "caar_num_variants", "caar_select_variant", "caar_selected_variant", "caar_variant_info",
+        "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_set_adaptive_window",
+        "caar_get_adaptive_window", "caar_adaptive_window_state", "caar_adaptive_window_reset", "caar_context_cache_window",
+        "caar_set_fused_steps", "caar_get_fused_steps", "caar_has_fused_steps", "caar_arrays_alloc_ex",
+        "caar_arrays_placement", "caar_create_ex", "caar_stream_copy", "caar_stream_copy_tuned",
+        "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_time_runs",
+        "caar_reciprocal", "caar_debug_dp3d_violations")
+    SYMBOLS = BOUNDARY_SYMBOLS + TUNING_SYMBOLS
 
     def __init__(self, path=LIB_PATH):
         if not os.path.exists(path):
@@ -114,6 +131,7 @@ class CaarLibrary:
             getattr(L, s)  # AttributeError if the library does not export it
         vp = C.c_void_p
         L.caar_supported.argtypes = [C.c_int, C.c_int]
+        L.caar_supported_ex.argtypes = [C.c_int, C.c_int, C.c_int]
         L.caar_debug_dp3d_violations.argtypes = [C.c_int]
         L.caar_debug_dp3d_violations.restype = C.c_longlong
         L.caar_strerror.argtypes = [C.c_int]

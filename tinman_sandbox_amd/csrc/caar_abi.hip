@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/caar.h"
+#include "../../include/caar_tuning.h"
 #include "caar_kernel_args.h"
 
 namespace caar {
@@ -435,6 +436,15 @@ long long caar_debug_dp3d_violations(int reset) {
 
 int caar_supported(int np, int nlev) { return caar::find_config(np, nlev) != nullptr; }
 
+int caar_supported_ex(int np, int nlev, int rsplit) {
+  const caar::Config* c = caar::find_config(np, nlev);
+  if (!c || rsplit < 0) return 0;
+  if (rsplit > 0) return 1;
+  // the Eulerian form: every specialised shape holds it; the run-time-level-count kernel (c->nlev == 0) up to 128 levels —
+  // beyond that it spills 65-90 VGPRs and is compiled into libcaar_hip_extra.so only (caar_np4.hip launch_np4_dyn)
+  return (c->nlev != 0 || nlev <= 128 || CAAR_EXTRA_NLEV) ? 1 : 0;
+}
+
 const char* caar_kernel_name(int np, int nlev) {
   const caar::Config* c = caar::find_config(np, nlev);
   return c ? c->variants[c->selected.load()].kernel : nullptr;
@@ -518,7 +528,7 @@ const char* caar_strerror(int rc) {
   switch (rc) {
     case CAAR_OK: return "ok";
     case CAAR_EINVAL: return "invalid argument";
-    case CAAR_EUNSUPPORTED: return "no kernel compiled for this (np, nlev)";
+    case CAAR_EUNSUPPORTED: return "no kernel compiled for this (np, nlev, rsplit) in this build of the library";
     case CAAR_ENODEVICE: return "no usable HIP device";
     case CAAR_ENOMEM: return "out of memory";
     default: return rc > 0 ? hipGetErrorString((hipError_t)rc) : "unknown caar error";
@@ -585,6 +595,7 @@ static int launch_with(const CaarDims* dims, const CaarArrays* dev, const double
     if ((size_t)*array_slot(dev, i) & 7) return CAAR_EINVAL;
   const caar::Config* cfg = caar::find_config(dims->np, dims->nlev);
   if (!cfg) return CAAR_EUNSUPPORTED;
+  if (!caar_supported_ex(dims->np, dims->nlev, p->rsplit)) return CAAR_EUNSUPPORTED;  // (before anything is enqueued)
   if (p->rsplit == 0 && (!p->hybi_dev || ((size_t)p->hybi_dev & 7))) return CAAR_EINVAL;
   const int n = p->nete - p->nets;
   if (n == 0) return CAAR_OK;
@@ -615,7 +626,7 @@ static int launch_with(const CaarDims* dims, const CaarArrays* dev, const double
   fill_args_impl(k, dims, dev, dvv_dev, p, ch);
   if (ev_before) (void)hipEventRecord(ev_before, (hipStream_t)stream);
   const hipError_t e = cfg->variants[ch.variant].launch(k, n, (hipStream_t)stream);
-  return e == hipErrorNotSupported ? CAAR_EUNSUPPORTED : (int)e;  // (a form this build does not hold: rsplit == 0 beyond 128 levels)
+  return e == hipErrorNotSupported ? CAAR_EUNSUPPORTED : (int)e;  // (belt and braces: caar_supported_ex above refuses first)
 }
 
 // nsteps calls as ONE launch if the chosen variant has a step-loop kernel (and the knob allows it): returns 1 if it was
@@ -1178,6 +1189,7 @@ int caar_run(CaarContext* c, const CaarParams* p) {
   if (!c || !p || !p->Dvv) return CAAR_EINVAL;
   HIP_TRY(hipSetDevice(c->device));
   if (p->rsplit == 0 && !p->hybi) return CAAR_EINVAL;
+  if (!caar_supported_ex(c->dims.np, c->dims.nlev, p->rsplit)) return CAAR_EUNSUPPORTED;
   CaarParams q = *p;
   const double* dvv_dev = nullptr;
   HIP_TRY(c->consts.sync(c->dims, &q, c->stream, &dvv_dev));
@@ -1189,6 +1201,7 @@ int caar_run(CaarContext* c, const CaarParams* p) {
 int caar_run_steps(CaarContext* c, const CaarParams* p, int nsteps, int rotate) {
   if (!c || !p || !p->Dvv || nsteps < 1) return CAAR_EINVAL;
   if (p->rsplit == 0 && !p->hybi) return CAAR_EINVAL;
+  if (!caar_supported_ex(c->dims.np, c->dims.nlev, p->rsplit)) return CAAR_EUNSUPPORTED;  // no capture is started
   HIP_TRY(hipSetDevice(c->device));
   CaarParams q = *p;
   const double* dvv_dev = nullptr;
@@ -1392,6 +1405,7 @@ int caar_run_mapped(CaarHostMapping* m, const CaarParams* p) {
   if (!m || !p || !p->Dvv) return CAAR_EINVAL;
   HIP_TRY(hipSetDevice(m->device));
   if (p->rsplit == 0 && !p->hybi) return CAAR_EINVAL;
+  if (!caar_supported_ex(m->dims.np, m->dims.nlev, p->rsplit)) return CAAR_EUNSUPPORTED;
   CaarParams q = *p;
   hipEvent_t done = nullptr;
   HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));

@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "../../include/caar.h"
+#include "../../include/caar_tuning.h"
 
 struct CaarArena {
   int device;

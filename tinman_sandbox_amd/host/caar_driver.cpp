@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "caar.h"
+#include "caar_tuning.h"  // caar_kernel_name, for the printed line (a tool, not a host binding)
 #include "homme_caar.hpp"
 
 namespace {

@@ -22,7 +22,6 @@
 #endif
 
 struct CaarContext;
-struct CaarPlacement;  // include/caar.h: where the device arrays are placed in HBM (NULL: the library's default)
 
 namespace Homme {
 
@@ -70,8 +69,6 @@ class DeviceSession {
   // per GPU when the element range is sharded (elements are independent: no exchange).
   // run()/state_norms() then take Control::nets/nete relative to the slab.
   DeviceSession(const TestData& data, int first_elem, int num_elems, int device);
-  // ... with the placement of the device arrays chosen by the caller (caar_create_ex)
-  DeviceSession(const TestData& data, int first_elem, int num_elems, int device, const CaarPlacement* placement);
   ~DeviceSession();
   DeviceSession(const DeviceSession&) = delete;
   DeviceSession& operator=(const DeviceSession&) = delete;
@@ -94,7 +91,7 @@ class DeviceSession {
   void download(TestData& data, bool all_arrays = false);
   // print_results_2norm's numbers for time level control.np1, computed on the device
   void state_norms(const TestData& data, real out[3]);
-  // milliseconds for `reps` back-to-back runs (HIP events on the session stream)
+  // milliseconds for `reps` back-to-back runs after one warm-up run (host wall clock around enqueue + wait)
   float time_runs(const TestData& data, int reps);
 
  private:
