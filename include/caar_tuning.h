@@ -63,9 +63,13 @@ long long caar_get_cache_window(void);
  * caar_adaptive_window_state: the policy in force for the array set whose derived_vn0 is `vn0_dev` (1 window, 0 all
  * streaming; -1 if the set is unknown) and, where the pointers are not NULL, the medians of the last probe (ms; 0 before
  * the first) and the number of probes decided so far.  caar_adaptive_window_reset forgets every array set (a host that
- * changes its call pattern need not call it: drift and re-probes follow; benchmarks that switch patterns use it). */
+ * changes its call pattern need not call it: drift and re-probes follow; benchmarks that switch patterns use it).  A set's
+ * entry is also forgotten when its memory is released (caar_arrays_free, caar_destroy). */
 int caar_set_adaptive_window(int on);
 int caar_get_adaptive_window(void);
+/* How often a launch has taken the tuner's mutex since the process started (tests/host_reentrancy.cpp: sub-range launches
+ * never do, whole-range launches only when a sample or a probe step is due). */
+long long caar_adaptive_window_lock_count(void);
 int caar_adaptive_window_state(const double *vn0_dev, double *ms_window, double *ms_streaming, long long *probes);
 int caar_adaptive_window_reset(void);
 

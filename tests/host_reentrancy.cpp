@@ -6,6 +6,10 @@
 //     must equal the single-thread call over the whole range bit for bit.
 // (2) The reference-signature operator functions of the shim (sphere_operators.hpp:9-16,
 //     compute_and_apply_rhs.hpp:11-17) against the oracle (test infrastructure: this program links it).
+// (3) (argv[3] = elements, default 0 = skip) The adaptive cache window is off the launch path: 8 host
+//     threads x 200 caar_launch calls on disjoint eighths of one device-resident array set, with the adaptive window on and
+//     with caar_set_adaptive_window(0): the tuner's mutex is never taken by a sub-range launch (caar_adaptive_window_lock_count
+//     does not move), the results are bit-identical, and the wall time is printed for both (the caller asserts 3 %).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +17,13 @@
 #include <thread>
 #include <vector>
 
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+
+#include "caar.h"
+#include "caar_tuning.h"
 #include "homme_caar.hpp"
 extern "C" {
 #include "caar_oracle.h"
@@ -128,6 +139,97 @@ int main(int argc, char** argv) {
   if (!h_ok || !o_ok) ++bad;
 
   shared.cleanup_data();
+
+  // ---- (3) the adaptive window and the launch path -----------------------------------------------------
+  const int big = argc > 3 ? std::atoi(argv[3]) : 0;
+  if (big > 0) {
+    num_elems = big;
+    TestData host;
+    host.init_data();
+    CaarDims d = {np, nlev, qsize_d, timelevels, big};
+    CaarContext* ctx = nullptr;
+    CaarArrays h, dev;
+    std::memcpy(&h, &host.arrays, sizeof(h));
+    if (caar_create(&ctx, &d, 0) || caar_upload(ctx, &h, 0, big) || caar_sync(ctx) || caar_device_arrays(ctx, &dev)) {
+      std::printf("(3) set-up failed\nFAILED\n");
+      return 1;
+    }
+    double* dvv_dev = nullptr;
+    if (hipMalloc((void**)&dvv_dev, sizeof(double) * np * np) != hipSuccess ||
+        hipMemcpy(dvv_dev, &host.deriv.Dvv[0][0], sizeof(double) * np * np, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    const int T = 8, CALLS = 200;
+    std::vector<hipStream_t> streams(T);
+    for (auto& st : streams)
+      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return 1;
+    CaarParams base = {};
+    base.n0 = 0; base.np1 = 1; base.nm1 = 2; base.qn0 = 0; base.dt2 = 1e-6; base.eta_ave_w = 0.0;  // (keeps 1 600 calls finite)
+    base.rrearth = host.constants.rrearth; base.Rwater_vapor = host.constants.Rwater_vapor; base.Rgas = host.constants.Rgas;
+    base.kappa = host.constants.kappa; base.ps0 = host.hvcoord.ps0; base.hyai0 = host.hvcoord.hyai[0];
+    base.Dvv = &host.deriv.Dvv[0][0]; base.rsplit = 1;
+    auto round = [&](int on, long long* locks) {
+      caar_set_adaptive_window(on);
+      (void)hipDeviceSynchronize();
+      const long long l0 = caar_adaptive_window_lock_count();
+      const auto t0 = std::chrono::steady_clock::now();
+      std::vector<std::thread> ths;
+      for (int t = 0; t < T; ++t)
+        ths.emplace_back([&, t] {
+          CaarParams p = base;
+          p.nets = int((long long)big * t / T);
+          p.nete = int((long long)big * (t + 1) / T);
+          for (int i = 0; i < CALLS; ++i)
+            if (caar_launch(&d, &dev, dvv_dev, &p, streams[t]) != CAAR_OK) std::abort();
+        });
+      for (auto& x : ths) x.join();
+      (void)hipDeviceSynchronize();
+      const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      *locks = caar_adaptive_window_lock_count() - l0;
+      return s;
+    };
+    // a whole-range launch first, so that the set HAS a tuner entry the sub-range launches look up
+    {
+      CaarParams p = base;
+      p.nets = 0;
+      p.nete = big;
+      for (int i = 0; i < 60; ++i)
+        if (caar_launch(&d, &dev, dvv_dev, &p, streams[0]) != CAAR_OK) return 1;
+      (void)hipDeviceSynchronize();
+    }
+    long long locks_on = 0, locks_off = 0, l;
+    double best_on = 1e30, best_off = 1e30;
+    round(1, &l);  // warm-up
+    for (int rep = 0; rep < 5; ++rep) {  // alternating, best of five each
+      best_off = std::fmin(best_off, round(0, &l));
+      locks_off += l;
+      best_on = std::fmin(best_on, round(1, &l));
+      locks_on += l;
+    }
+    std::printf("(3) %d threads x %d sub-range launches on %d elements: adaptive on %.6f s, off %.6f s (ratio %.4f); tuner mutex taken %lld / %lld times\n",
+                T, CALLS, big, best_on, best_off, best_on / best_off, locks_on, locks_off);
+    if (locks_on != 0 || locks_off != 0) {
+      std::printf("(3) a sub-range launch took the tuner's mutex\n");
+      ++bad;
+    }
+    // whole-range launches from one thread: the mutex only where a sample or a probe step is due
+    {
+      CaarParams p = base;
+      p.nets = 0;
+      p.nete = big;
+      caar_adaptive_window_reset();
+      const long long l0 = caar_adaptive_window_lock_count();
+      const int N = 400;
+      for (int i = 0; i < N; ++i)
+        if (caar_launch(&d, &dev, dvv_dev, &p, streams[0]) != CAAR_OK) return 1;
+      (void)hipDeviceSynchronize();
+      const long long took = caar_adaptive_window_lock_count() - l0;
+      std::printf("(3) %d whole-range launches: tuner mutex taken %lld times\n", N, took);
+      if (took <= 0 || took > N * 3 / 4) ++bad;  // (first call + 2-3 of every 8 + the 16 calls of the first probe)
+    }
+    for (auto& st : streams) (void)hipStreamDestroy(st);
+    (void)hipFree(dvv_dev);
+    caar_destroy(ctx);
+    host.cleanup_data();
+  }
   std::printf(bad ? "FAILED\n" : "OK\n");
   return bad ? 1 : 0;
 }

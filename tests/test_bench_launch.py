@@ -17,15 +17,16 @@ def _env(**kw):
     return env
 
 
-def test_plain_multi_gpu_invocation_starts_its_own_ranks():
+@pytest.mark.parametrize("n", [3, 8])
+def test_plain_multi_gpu_invocation_starts_its_own_ranks(n):
     import torch
     if torch.cuda.is_available():
         pytest.skip("on a GPU box the plain launch is covered by tests/test_bench_gpu.py")
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--steps", "2"], capture_output=True, text=True, timeout=300,
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--steps", "2"], capture_output=True, text=True, timeout=300,
                        env=_env())
-    # no GPU here: every one of the three ranks gets as far as the device check and says so; no CPU fallback, rc != 0
+    # no GPU here: every one of the n ranks gets as far as the device check and says so; no CPU fallback, rc != 0
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs MI355X GPUs") == 3, r.stderr[-2000:]
+    assert r.stderr.count("bench.py needs MI355X GPUs") == n, r.stderr[-2000:]
     assert "must be launched with" not in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 

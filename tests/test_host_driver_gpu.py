@@ -195,13 +195,13 @@ def _build_host_test(tmp_path, source, np_=4, nlev=72, oracle=True):
     suffix = "" if (np_, nlev) == (4, 72) else "_np%d_nlev%d" % (np_, nlev)
     exe = str(tmp_path / os.path.splitext(source)[0])
     subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", "-DCAAR_NP=%d" % np_, "-DCAAR_PLEV=%d" % nlev,
-                    "-I" + os.path.join(ROOT, "include"), "-I" + host, "-I" + os.path.join(ROOT, "oracle"),
+                    "-I" + os.path.join(ROOT, "include"), "-I" + host, "-I" + os.path.join(ROOT, "oracle"), "-I/opt/rocm/include",
                     os.path.join(ROOT, "tests", source),
                     "-L" + host, "-lhomme_caar" + suffix, "-Wl,-rpath," + host] +
                    (["-L" + os.path.join(ROOT, "oracle"), "-lcaar_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")] if oracle else []) +
                    ["-L" + os.path.join(ROOT, "tinman_sandbox_amd", "csrc"), "-lcaar_hip",
-                    "-Wl,-rpath," + os.path.join(ROOT, "tinman_sandbox_amd", "csrc"), "-Wl,-rpath,/opt/rocm/lib",
-                    "-o", exe], check=True)
+                    "-Wl,-rpath," + os.path.join(ROOT, "tinman_sandbox_amd", "csrc"), "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
     return exe
 
 
@@ -301,3 +301,17 @@ def test_shim_is_reentrant_and_defines_the_reference_operator_functions(tmp_path
     r = subprocess.run([exe, "37", "4"], capture_output=True, text=True, timeout=300, env=_env(CAAR_SHIM_RESIDENT="1"))
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
     assert "== bitwise the single call (resident mode)" in r.stdout
+
+
+def test_adaptive_window_is_off_the_launch_path(tmp_path):
+    """tests/host_reentrancy.cpp part (3) — 8 host threads x 200 caar_launch calls on disjoint eighths of one
+    2 000-element array set (430 MB: large enough for the adaptive window to apply): the tuner's mutex is never taken by a
+    sub-range launch, whole-range launches take it only where a sample or a probe step is due, and the wall time with the
+    adaptive window on is within 3 % of caar_set_adaptive_window(0) (best of five alternating rounds each)."""
+    exe = _build_host_test(tmp_path, "host_reentrancy.cpp")
+    r = subprocess.run([exe, "9", "2", "2000"], capture_output=True, text=True, timeout=600, env=_env())
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    m = re.search(r"adaptive on ([0-9.]+) s, off ([0-9.]+) s \(ratio ([0-9.]+)\); tuner mutex taken 0 / 0 times", r.stdout)
+    assert m, r.stdout
+    print(r.stdout)
+    assert float(m.group(3)) <= 1.03, r.stdout

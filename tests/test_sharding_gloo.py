@@ -74,6 +74,16 @@ def test_two_rank_sharding_gloo(tmp_path, total_elems):
     assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
 
 
+def test_eight_rank_sharding_gloo(tmp_path):
+    """The world size the driver's scaling run ends at: eight gloo ranks (CPU), 19 elements — slabs of 3, 3, 3, 3, 3, 3, 1, 0:
+    a short and an EMPTY last rank — tile the range, each slab's result equals the unsharded one, and the norm / max / gather
+    collectives bench.py uses agree on every rank."""
+    world = 8
+    mp.spawn(_worker, args=(world, _free_port(), 19, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
+    assert [sharding.shard_range(100000, r, 8) for r in (0, 7)] == [(0, 12500), (87500, 100000)]   # configs[2]
+
+
 def test_single_process_paths():
     per = torch.tensor([[1.0, 4.0, 9.0], [3.0, 12.0, 16.0]])
     assert sharding.gather_slab_norms(per) == (2.0, 4.0, 5.0)

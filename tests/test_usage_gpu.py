@@ -664,16 +664,20 @@ def test_debug_build_counts_nonpositive_layer_thickness(tmp_path):
     assert r.returncode == 0 and "DEBUG-BUILD-OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
-def test_adaptive_cache_window_changes_the_policy_not_the_results():
-    """include/caar.h "Adaptive window": the library times both cache policies of the default kernel on the host's own call
-    pattern and keeps the faster.  Policies are the same kernel with another cache hint, so results must not move: 130 calls
-    with the adaptive window on (first probe at calls 48-61: seven all-streaming calls in between) equal 130 calls with the
-    window forced, bit for bit; afterwards the library reports a decision that agrees with what it measured."""
+@pytest.mark.parametrize("nlev", [72, 128])
+def test_adaptive_cache_window_changes_the_policy_not_the_results(nlev):
+    """include/caar_tuning.h "Adaptive window": the library times both cache policies of the default kernel on the host's own
+    call pattern and keeps the faster.  The all-streaming policy launches the streaming twin of the default kernel (variant 1:
+    another instantiation, POL = 1, its own XCD mapping) — results must not move: 130 calls with the adaptive window on (first
+    probe at calls 48-61: seven all-streaming calls in between) equal 130 calls with the window forced, bit for bit, at both
+    level counts that have a twin; afterwards the library reports a decision that agrees with what it measured, and forgets
+    the set when its memory is released."""
     import ctypes as C
+    import gc
     lib = tsa.library().lib
     E = 3000
-    a = tsa.TestData().init_data(E, 4, 72, device="cuda")
-    b = tsa.TestData().init_data(E, 4, 72, device="cuda")
+    a = tsa.TestData().init_data(E, 4, nlev, device="cuda")
+    b = tsa.TestData().init_data(E, 4, nlev, device="cuda")
     for d in (a, b):
         d.constants.eta_ave_w = 0.01   # (no rotation of the time levels: the np1 state is idempotent, the accumulators grow linearly)
     assert lib.caar_get_adaptive_window() == 1
@@ -698,5 +702,10 @@ def test_adaptive_cache_window_changes_the_policy_not_the_results():
     assert state == (1 if w.value <= s.value * 1.003 else 0)
     # an array set no whole-range launch was seen of, and the forced-off switch
     assert lib.caar_adaptive_window_state(C.c_void_p(b.arrays["elem_derived_vn0"].data_ptr()), None, None, None) == -1
+    # releasing the arrays drops the set's entry (a later allocation at the same address must not inherit its policy)
+    key = a.arrays["elem_derived_vn0"].data_ptr()
+    assert a.arrays.arena is not None
+    del a
+    gc.collect()
+    assert lib.caar_adaptive_window_state(C.c_void_p(key), None, None, None) == -1
     lib.caar_adaptive_window_reset()
-    assert lib.caar_adaptive_window_state(C.c_void_p(a.arrays["elem_derived_vn0"].data_ptr()), None, None, None) == -1

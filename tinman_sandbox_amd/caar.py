@@ -114,7 +114,8 @@ class CaarLibrary:
     TUNING_SYMBOLS = (
         "caar_kernel_name", "caar_num_variants", "caar_select_variant", "caar_selected_variant", "caar_variant_info",
         "caar_set_xcd_chunked", "caar_set_cache_window", "caar_get_cache_window", "caar_set_adaptive_window",
-        "caar_get_adaptive_window", "caar_adaptive_window_state", "caar_adaptive_window_reset", "caar_context_cache_window",
+        "caar_get_adaptive_window", "caar_adaptive_window_state", "caar_adaptive_window_reset", "caar_adaptive_window_lock_count",
+        "caar_context_cache_window",
         "caar_set_fused_steps", "caar_get_fused_steps", "caar_has_fused_steps", "caar_arrays_alloc_ex",
         "caar_arrays_placement", "caar_create_ex", "caar_stream_copy", "caar_stream_copy_tuned",
         "caar_stream_copy_tuned_variants", "caar_stream_copy_tuned_info", "caar_traffic_skeleton", "caar_time_runs",
@@ -171,6 +172,7 @@ class CaarLibrary:
         L.caar_set_cache_window.argtypes = [C.c_longlong]
         L.caar_get_cache_window.restype = C.c_longlong
         L.caar_adaptive_window_state.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+        L.caar_adaptive_window_lock_count.restype = C.c_longlong
         L.caar_context_cache_window.argtypes = [vp]
         L.caar_context_cache_window.restype = C.c_longlong
         L.caar_selected_variant.argtypes = [C.c_int, C.c_int]

@@ -158,6 +158,7 @@ struct LaunchChoice {
   int variant;
   int xcd_chunked;
   long long cache_window;
+  bool adapted;  // the adaptive window's policy is already folded in (apply_window_policy): launch_with leaves it alone
 };
 static LaunchChoice launch_choice(const Config* cfg) {
   LaunchChoice c;
@@ -165,6 +166,7 @@ static LaunchChoice launch_choice(const Config* cfg) {
   c.xcd_chunked = g_xcd_chunked.load(std::memory_order_relaxed);
   if (c.xcd_chunked < 0) c.xcd_chunked = cfg && cfg->variants[c.variant].prefers_xcd_chunked ? 1 : 0;
   c.cache_window = g_cache_window.load(std::memory_order_relaxed);
+  c.adapted = false;
   return c;
 }
 }  // namespace caar
@@ -186,16 +188,28 @@ static LaunchChoice launch_choice(const Config* cfg) {
 //     of the measured calls; the window on ties) becomes the policy.
 //   * A launch inside a stream capture, on a sub-range of the elements, or of a captured graph uses the set's current
 //     policy and measures nothing.
-// Both policies are the same kernel (cache_count == 0 is all-streaming) and give identical results.
+// Both policies give identical results (the all-streaming twin performs the same roundings).
+//
+// Locking (round 5): the policy of a set is PUBLISHED in atomics that launches read without a lock — sub-range launches
+// (HOMME's horizontal-OpenMP threads), captures and graph re-validation only ever do that.  A whole-range launch also counts
+// itself down on an atomic; WindowTuners::mu is taken only when the countdown says the state machine has work for this
+// call: a passive sample is due (two consecutive calls in every kSampleEvery), a probe is running, or the set is new.
+// Events are recorded and queried under the mutex only, so a reset / LRU restart can never destroy an event another thread
+// is about to record.
 namespace caar {
 struct WindowTuner {
   static constexpr int kFirstProbe = 48, kWarm = 3, kMeas = 4, kHalf = kWarm + kMeas, kReprobe = 96, kReprobeWindow = 4096, kSampleEvery = 8;
   static constexpr int kProbeEvents = 2 * kHalf + 1;  // one in front of every probe call + one in front of the call after
   static constexpr double kDrift = 0.03, kTie = 0.003;
-  const void* key = nullptr;  // CaarArrays::elem_derived_vn0 of the set
-  int device = -1;
+  // published, read lock-free (a reader that races with a restart may see another set's policy for one call: both policies
+  // compute the same thing)
+  std::atomic<const void*> key{nullptr};  // CaarArrays::elem_derived_vn0 of the set
+  std::atomic<int> device{-1};
+  std::atomic<int> use_window{1};
+  std::atomic<long long> idle{0};  // whole-range calls that may still pass without the mutex
+  // everything below: under WindowTuners::mu
   long long calls = 0, since_decision = 0, probes = 0, last_use = 0;
-  int use_window = 1;
+  long long idle_granted = 0;                  // what `idle` was last set to: that many calls went by uncounted
   double ms_window = 0.0, ms_streaming = 0.0;  // medians of the last probe (call-to-call times)
   double base_ms = 0.0, cur_ms = 0.0;          // the current policy's call-to-call time: at the decision / smoothed since
   // probe: step 0 = idle; 1 .. 2 kHalf = that call of the probe is next; 2 kHalf + 1 = the closing event is next;
@@ -206,27 +220,32 @@ struct WindowTuner {
   int sample = 0;  // 0 idle, 1 = first event recorded at the previous call, 2 = both recorded, waiting
   bool broken = false;
 
-  void drop_events() {
-    for (auto& x : probe_ev)
-      if (x) (void)hipEventDestroy(x);
-    for (auto& x : sample_ev)
-      if (x) (void)hipEventDestroy(x);
-  }
-  void restart(const void* k, int dev) {
-    drop_events();
-    *this = WindowTuner();
-    key = k;
-    device = dev;
+  void restart(const void* k, int dev) {  // (the events are kept for the next set: creating them is the expensive part)
+    key.store(nullptr, std::memory_order_relaxed);
+    calls = since_decision = probes = last_use = idle_granted = 0;
+    ms_window = ms_streaming = base_ms = cur_ms = 0.0;
+    step = probe_first = sample = 0;
+    broken = false;
+    use_window.store(1, std::memory_order_relaxed);
+    idle.store(0, std::memory_order_relaxed);
+    device.store(dev, std::memory_order_relaxed);
+    key.store(k, std::memory_order_release);
   }
 };
 struct WindowTuners {
   std::mutex mu;
   WindowTuner t[8];
   long long tick = 0;
+  std::atomic<long long> locked_calls{0};  // how often the mutex was taken on the launch path (tests, host_reentrancy.cpp)
 };
 static WindowTuners* window_tuners() {
   static WindowTuners* w = new WindowTuners();  // never destroyed: no HIP calls from static destructors at exit
   return w;
+}
+static WindowTuner* find_tuner(WindowTuners* all, const void* key, int device) {
+  for (auto& x : all->t)
+    if (x.key.load(std::memory_order_acquire) == key && x.device.load(std::memory_order_relaxed) == device) return &x;
+  return nullptr;
 }
 static double median_of(float* v, int n) {
   for (int i = 1; i < n; ++i)
@@ -237,31 +256,42 @@ static double median_of(float* v, int n) {
     }
   return n % 2 ? v[n / 2] : 0.5 * (v[n / 2 - 1] + v[n / 2]);
 }
+// forget the set whose derived_vn0 lies at `key` (its memory is being released: a later allocation at the same address
+// must not inherit its policy and counters); caar_arrays_free and caar_destroy call this
+void window_tuner_forget(const void* key, int device) {
+  if (!key) return;
+  WindowTuners* all = window_tuners();
+  std::lock_guard<std::mutex> g(all->mu);
+  for (auto& x : all->t)
+    if (x.key.load(std::memory_order_relaxed) == key && x.device.load(std::memory_order_relaxed) == device) x.restart(nullptr, -1);
+}
 }  // namespace caar
 static std::atomic<int> g_adaptive_window{1};
 
-// The policy in force for an array set (1 = window: also for a set no whole-range launch has been seen of)
+// The policy in force for an array set (1 = window: also for a set no whole-range launch has been seen of).  Lock-free.
 static int adaptive_window_current(const CaarArrays* dev, int device) {
-  caar::WindowTuners* all = caar::window_tuners();
-  std::lock_guard<std::mutex> g(all->mu);
-  for (auto& x : all->t)
-    if (x.key == dev->elem_derived_vn0 && x.device == device) return x.use_window;
-  return 1;
+  const caar::WindowTuner* t = caar::find_tuner(caar::window_tuners(), dev->elem_derived_vn0, device);
+  return t ? t->use_window.load(std::memory_order_relaxed) : 1;
 }
 
 // Decides the policy of one whole-range launch on a hybrid kernel and, when the tuner wants a time stamp in front of this
-// call, hands back the event to record there.  Returns 1: use the window, 0: all streaming.
-static int adaptive_window_policy(const CaarArrays* dev, int device, hipStream_t stream, hipEvent_t* before) {
+// call, records it on `stream` (under the mutex).  Returns 1: use the window, 0: all streaming.
+static int adaptive_window_policy(const CaarArrays* dev, int device, hipStream_t stream) {
   using caar::WindowTuner;
-  *before = nullptr;
+  caar::WindowTuners* all = caar::window_tuners();
+  {
+    // the common case: nothing is due for this call
+    WindowTuner* t = caar::find_tuner(all, dev->elem_derived_vn0, device);
+    if (t && t->idle.fetch_sub(1, std::memory_order_relaxed) > 0) return t->use_window.load(std::memory_order_relaxed);
+  }
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
-  caar::WindowTuners* all = caar::window_tuners();
+  all->locked_calls.fetch_add(1, std::memory_order_relaxed);
   std::lock_guard<std::mutex> g(all->mu);
   WindowTuner* t = nullptr;
   WindowTuner* lru = &all->t[0];
   for (auto& x : all->t) {
-    if (x.key == dev->elem_derived_vn0 && x.device == device) t = &x;
+    if (x.key.load(std::memory_order_relaxed) == dev->elem_derived_vn0 && x.device.load(std::memory_order_relaxed) == device) t = &x;
     if (x.last_use < lru->last_use) lru = &x;
   }
   if (!t) {
@@ -270,19 +300,25 @@ static int adaptive_window_policy(const CaarArrays* dev, int device, hipStream_t
     t->restart(dev->elem_derived_vn0, device);
   }
   t->last_use = ++all->tick;
-  if (capturing) return t->use_window;
+  if (capturing) return t->use_window.load(std::memory_order_relaxed);  // (idle stays <= 0: the next plain call comes here again)
   constexpr int kHalf = WindowTuner::kHalf;
-  auto event = [&](hipEvent_t& e) -> hipEvent_t {
-    if (!e && hipEventCreate(&e) != hipSuccess) {
-      e = nullptr;
+  auto stamp = [&](hipEvent_t& e) -> bool {  // record `e` in front of this call
+    if (!e && hipEventCreate(&e) != hipSuccess) e = nullptr;
+    if (!e || hipEventRecord(e, stream) != hipSuccess) {
       t->broken = true;
+      return false;
     }
-    return e;
+    return true;
   };
   auto elapsed = [&](hipEvent_t a, hipEvent_t b, float* ms) {
     *ms = 0.f;
     return hipEventElapsedTime(ms, a, b) == hipSuccess && *ms > 0.f;
   };
+  // the calls that went by on the fast path since the mutex was last held, and this one
+  t->calls += t->idle_granted + 1;
+  t->since_decision += t->idle_granted + 1;
+  t->idle_granted = 0;
+  int use = t->use_window.load(std::memory_order_relaxed);
   // the passive sample of the current policy: completed?
   if (t->sample == 2 && hipEventQuery(t->sample_ev[1]) == hipSuccess) {
     float ms;
@@ -302,50 +338,59 @@ static int adaptive_window_policy(const CaarArrays* dev, int device, hipStream_t
       const double first = caar::median_of(m[0], WindowTuner::kMeas), second = caar::median_of(m[1], WindowTuner::kMeas);
       t->ms_window = t->probe_first ? first : second;
       t->ms_streaming = t->probe_first ? second : first;
-      t->use_window = t->ms_window <= t->ms_streaming * (1.0 + WindowTuner::kTie) ? 1 : 0;
-      t->base_ms = t->cur_ms = t->use_window ? t->ms_window : t->ms_streaming;
+      use = t->ms_window <= t->ms_streaming * (1.0 + WindowTuner::kTie) ? 1 : 0;
+      t->use_window.store(use, std::memory_order_relaxed);
+      t->base_ms = t->cur_ms = use ? t->ms_window : t->ms_streaming;
       ++t->probes;
     }
     t->step = 0;
     t->broken = false;
-    t->since_decision = 0;
+    t->since_decision = 0;  // (also after a probe that had to be discarded: the first-probe test below re-arms on it)
     t->sample = 0;
   }
   (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error code
-  ++t->calls;
-  ++t->since_decision;
   if (t->step == 0) {
-    const bool first = t->probes == 0 && t->calls == WindowTuner::kFirstProbe;
+    // (a first probe that was discarded — an event could not be created, a non-positive interval — leaves probes == 0 and
+    // since_decision reset: it is tried again kFirstProbe calls later, not never)
+    const bool first = t->probes == 0 && t->since_decision >= WindowTuner::kFirstProbe;
     const bool drift = t->probes > 0 && t->base_ms > 0.0 && t->cur_ms > t->base_ms * (1.0 + WindowTuner::kDrift) && t->since_decision > 24;
     // (while the window is the policy a re-probe costs seven all-streaming calls, so it is rare: it only guards against a
     // first probe that was taken during a fresh process's ramp-up, which favours whichever policy ran second)
-    const bool again = t->probes > 0 && t->since_decision >= (t->use_window ? WindowTuner::kReprobeWindow : WindowTuner::kReprobe);
+    const bool again = t->probes > 0 && t->since_decision >= (use ? WindowTuner::kReprobeWindow : WindowTuner::kReprobe);
     if (first || drift || again) {
       t->step = 1;
       t->sample = 0;
-      t->probe_first = t->use_window ? 0 : 1;  // the OTHER policy first, the current one second
+      t->probe_first = use ? 0 : 1;  // the OTHER policy first, the current one second
     }
   }
+  int policy = use;
   if (t->step >= 1 && t->step <= 2 * kHalf) {
     const int s = t->step++;  // 1 .. 2 kHalf
-    *before = event(t->probe_ev[s - 1]);
-    return (s - 1) / kHalf == 0 ? t->probe_first : 1 - t->probe_first;
-  }
-  if (t->step == 2 * kHalf + 1) {  // the call after the probe: its start closes the last measured interval
-    *before = event(t->probe_ev[2 * kHalf]);
+    (void)stamp(t->probe_ev[s - 1]);
+    policy = (s - 1) / kHalf == 0 ? t->probe_first : 1 - t->probe_first;
+  } else if (t->step == 2 * kHalf + 1) {  // the call after the probe: its start closes the last measured interval
+    (void)stamp(t->probe_ev[2 * kHalf]);
     t->step = 2 * kHalf + 2;
-    return t->use_window;
-  }
-  if (t->step == 0) {
+  } else if (t->step == 0) {
     if (t->sample == 1) {
-      *before = event(t->sample_ev[1]);
-      t->sample = *before ? 2 : 0;
+      t->sample = stamp(t->sample_ev[1]) ? 2 : 0;
     } else if (t->sample == 0 && t->calls % WindowTuner::kSampleEvery == 0) {
-      *before = event(t->sample_ev[0]);
-      t->sample = *before ? 1 : 0;
+      t->sample = stamp(t->sample_ev[0]) ? 1 : 0;
     }
   }
-  return t->use_window;
+  // how many of the following calls have nothing to do here: none while a probe runs or a sample is open, else up to the
+  // next sample slot or the first probe, whichever comes first
+  long long grant = 0;
+  if (t->step == 0 && t->sample == 0) {
+    grant = WindowTuner::kSampleEvery - 1 - t->calls % WindowTuner::kSampleEvery;
+    if (t->probes == 0) {
+      const long long to_first = WindowTuner::kFirstProbe - 1 - t->since_decision;
+      if (to_first < grant) grant = to_first < 0 ? 0 : to_first;
+    }
+  }
+  t->idle_granted = grant;
+  t->idle.store(grant, std::memory_order_relaxed);
+  return policy;
 }
 
 // The cache window is a budget of the DEVICE: contexts that live on the same device share it in proportion to the bytes
@@ -486,14 +531,16 @@ int caar_adaptive_window_state(const double* vn0_dev, double* ms_window, double*
   caar::WindowTuners* all = caar::window_tuners();
   std::lock_guard<std::mutex> g(all->mu);
   for (auto& t : all->t)
-    if (t.key && t.key == (const void*)vn0_dev) {
+    if (vn0_dev && t.key.load(std::memory_order_relaxed) == (const void*)vn0_dev) {
       if (ms_window) *ms_window = t.ms_window;
       if (ms_streaming) *ms_streaming = t.ms_streaming;
       if (probes) *probes = t.probes;
-      return t.use_window;
+      return t.use_window.load(std::memory_order_relaxed);
     }
   return -1;
 }
+
+long long caar_adaptive_window_lock_count(void) { return caar::window_tuners()->locked_calls.load(std::memory_order_relaxed); }
 
 int caar_adaptive_window_reset(void) {
   caar::WindowTuners* all = caar::window_tuners();
@@ -572,8 +619,26 @@ static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const Caar
 
 static int launch_with(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev, const CaarParams* p,
                        void* stream, const caar::LaunchChoice* forced, bool tune = true);
-static int adaptive_window_policy(const CaarArrays* dev, int device, hipStream_t stream, hipEvent_t* before);
-static int adaptive_window_current(const CaarArrays* dev, int device);
+
+// Is there a policy to decide for this launch?  Only where there is something to decide: a hybrid kernel with a window, the
+// vertically Lagrangian form, and a data set that does not fit the 256 MB cache whole (one that does is served from it under
+// either policy, and the small-element hosts that live in the launch-latency regime are not charged the tuner's microseconds).
+static bool adaptive_applies(const caar::Config* cfg, const caar::LaunchChoice& ch, const CaarDims* dims, const CaarParams* p) {
+  return cfg->variants[ch.variant].hybrid && ch.cache_window > 0 && p->rsplit != 0 && g_adaptive_window.load(std::memory_order_relaxed) &&
+         caar_algorithmic_bytes(dims->np, dims->nlev, 0) * (long long)dims->num_elems > (256LL << 20);
+}
+// Bakes a policy into a launch choice: all-streaming = an empty window and, where the variant names one, the all-streaming
+// kernel of the same shape with the element mapping it was measured faster with (unless the host fixed the mapping).
+static void apply_window_policy(const caar::Config* cfg, caar::LaunchChoice& ch, int use_window) {
+  ch.adapted = true;
+  if (use_window) return;
+  ch.cache_window = 0;
+  const int twin = cfg->variants[ch.variant].streaming_twin;
+  if (twin >= 0 && twin < cfg->count) {
+    ch.variant = twin;
+    if (g_xcd_chunked.load(std::memory_order_relaxed) < 0) ch.xcd_chunked = cfg->variants[twin].prefers_xcd_chunked ? 1 : 0;
+  }
+}
 
 int caar_launch(const CaarDims* dims, const CaarArrays* dev, const double* dvv_dev,
                 const CaarParams* p, void* stream) {
@@ -602,29 +667,15 @@ static int launch_with(const CaarDims* dims, const CaarArrays* dev, const double
 
   caar::LaunchChoice ch = forced ? *forced : caar::launch_choice(cfg);  // the knobs, read once
   // the adaptive window: whole-range launches of a hybrid kernel with a window to switch off (see adaptive_window_policy)
-  hipEvent_t ev_before = nullptr;
-  // (only where there is something to decide: a data set that fits the 256 MB cache whole is served from it under either
-  // policy, and the small-element hosts that live in the launch-latency regime are not charged the tuner's microseconds)
-  if (cfg->variants[ch.variant].hybrid && ch.cache_window > 0 && p->rsplit != 0 && g_adaptive_window.load(std::memory_order_relaxed) &&
-      caar_algorithmic_bytes(dims->np, dims->nlev, 0) * (long long)dims->num_elems > (256LL << 20)) {
+  if (!ch.adapted && adaptive_applies(cfg, ch, dims, p)) {
     int device = 0;
     if (hipGetDevice(&device) == hipSuccess) {
-      const bool measure = tune && n == dims->num_elems;  // else: the set's current policy, nothing measured
-      if (!(measure ? adaptive_window_policy(dev, device, (hipStream_t)stream, &ev_before) : adaptive_window_current(dev, device))) {
-        ch.cache_window = 0;
-        const int twin = cfg->variants[ch.variant].streaming_twin;  // the all-streaming kernel of the same shape, if there is one
-        if (twin >= 0 && twin < cfg->count) {
-          ch.variant = twin;
-          // ... with the element mapping the twin was measured faster with (round-robin for the all-streaming shapes),
-          // unless the host fixed the mapping (caar_set_xcd_chunked)
-          if (g_xcd_chunked.load(std::memory_order_relaxed) < 0) ch.xcd_chunked = cfg->variants[twin].prefers_xcd_chunked ? 1 : 0;
-        }
-      }
+      const bool measure = tune && n == dims->num_elems;  // else: the set's current policy (lock-free), nothing measured
+      apply_window_policy(cfg, ch, measure ? adaptive_window_policy(dev, device, (hipStream_t)stream) : adaptive_window_current(dev, device));
     }
   }
   caar::KernelArgs k;
   fill_args_impl(k, dims, dev, dvv_dev, p, ch);
-  if (ev_before) (void)hipEventRecord(ev_before, (hipStream_t)stream);
   const hipError_t e = cfg->variants[ch.variant].launch(k, n, (hipStream_t)stream);
   return e == hipErrorNotSupported ? CAAR_EUNSUPPORTED : (int)e;  // (belt and braces: caar_supported_ex above refuses first)
 }
@@ -1219,6 +1270,10 @@ int caar_run_steps(CaarContext* c, const CaarParams* p, int nsteps, int rotate) 
     int rc = CAAR_OK;
     if (try_fused_steps(&c->dims, &c->dev, dvv_dev, &q, nsteps, rotate, c->stream, cfg, now, &rc)) return rc;
   }
+  // ... and for the same cache POLICY: the adaptive window's current choice for this array set is folded into `now` (lock-free
+  // read), so a policy the tuner has flipped since the capture re-captures the graph instead of replaying the old launches
+  // for ever.  (Graph launches themselves measure nothing: a set driven only through this path keeps the default policy.)
+  if (cfg && adaptive_applies(cfg, now, &c->dims, &q)) apply_window_policy(cfg, now, adaptive_window_current(&c->dev, c->device));
   bool same = c->steps_exec && c->steps_n == nsteps && c->steps_rotate == (rotate != 0) &&
               c->steps_choice.variant == now.variant && c->steps_choice.xcd_chunked == now.xcd_chunked &&
               c->steps_choice.cache_window == now.cache_window && std::memcmp(c->steps_dvv, p->Dvv, nd) == 0;

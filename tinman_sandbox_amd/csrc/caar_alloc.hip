@@ -50,7 +50,12 @@ struct CaarArena {
   void* plain[CAAR_NUM_ARRAYS];                           // fallback: one hipMalloc per array
   long long pool_chunks, chunk_bytes;
   int teardown_errors;  // hipMemUnmap / hipMemRelease / hipMemAddressFree calls that failed (reported by caar_arrays_free)
+  const void* vn0;      // elem_derived_vn0 of the set: the key of its adaptive-window tuner (caar_abi.hip), dropped with the arena
 };
+
+namespace caar {
+void window_tuner_forget(const void* key, int device);  // caar_abi.hip
+}
 
 namespace {
 
@@ -272,6 +277,7 @@ int caar_arrays_alloc_ex(CaarArena** arena, const CaarDims* dims, int device, co
   a->mapped = 0;
   a->pool_chunks = a->chunk_bytes = 0;
   a->teardown_errors = 0;
+  a->vn0 = nullptr;
   std::memset(a->plain, 0, sizeof(a->plain));
   size_t bytes[CAAR_NUM_ARRAYS], total = 0;
   for (int i = 0; i < CAAR_NUM_ARRAYS; ++i) {
@@ -291,6 +297,7 @@ int caar_arrays_alloc_ex(CaarArena** arena, const CaarDims* dims, int device, co
       out[i] = static_cast<double*>(a->plain[i]);
     }
   }
+  a->vn0 = out_dev->elem_derived_vn0;
   *arena = a;
   return CAAR_OK;
 }
@@ -303,6 +310,7 @@ int caar_arrays_free(CaarArena* a) {
   if (!a) return CAAR_EINVAL;
   DeviceGuard guard;  // may run from a finaliser on whatever thread and device happen to be current
   (void)guard.enter(a->device);
+  caar::window_tuner_forget(a->vn0, a->device);  // a later set at the same address starts from the default policy
   release_vmm(a);
   for (int i = 0; i < CAAR_NUM_ARRAYS; ++i)
     if (a->plain[i] && hipFree(a->plain[i]) != hipSuccess) {
