@@ -207,61 +207,31 @@ def test_one_rank_under_rccl_takes_the_collective_path():
 
 def test_performance_lower_bounds():
     """A guard against codegen regressions: the kernels' speed is pinned to one hipcc through a
-    17-parameter template, and nothing else in the suite would notice a silent 10 % loss.  Fresh arrays per configuration,
-    60 untimed launches (a fresh process ramps up), best of three blocks of 30 launches, HIP events on the launch stream;
-    the adaptive window is off (the window policy is forced) so that the figures do not depend on a probe's outcome.
-    Thresholds sit ~4 % under the worst box of rounds 4-5 (boxes differ by a few per cent; placement by 3-5 %):
-      NP=4 NLEV=72, 10 000 elements   window policy >= 0.84, all-streaming twin >= 0.74 of the 8 TB/s HBM peak
-      NP=4 NLEV=128, 12 500 elements  >= 0.78          NP=8 NLEV=72, 20 000 elements  >= 0.74
+    17-parameter template, and nothing else in the suite would notice a silent 10 % loss.  Every configuration in a FRESH
+    process (tools/perf_guard.py: placement of the arrays moves the rate by 3-5 %, and arrays allocated late in a long-running
+    process land badly — measured in this very test: NLEV=128 0.81 in a fresh process, 0.74 after another set had been
+    allocated and freed), spun up until stable, best of three blocks of 30 launches, HIP events on the launch stream, the
+    adaptive window off (window policy forced).
+    Boxes of the pool differ by up to 10 % in what their memory system delivers (round 5: 0.885 on one box, 0.817 on the next
+    for the same binary), so each bandwidth-bound figure has two floors and passes if it clears EITHER: the fraction of the
+    8 TB/s peak (~4 % under the fast boxes of rounds 4-5, as VERDICT r04 #4 asked) or the rate relative to the same process's
+    best tuned device copy (~5 % under what rounds 4-5 measured: 1.08-1.09 / 0.955-0.965 / 1.01 / 0.955), which holds across
+    boxes.  The step loop is bound by instruction issue, not by the memory system: one absolute ceiling.
+      NP=4 NLEV=72, 10 000 elements   window policy >= 0.84 or 1.03 x copy, all-streaming twin >= 0.74 or 0.91 x copy
+      NP=4 NLEV=128, 12 500 elements  >= 0.78 or 0.96 x copy          NP=8 NLEV=72, 20 000 elements  >= 0.74 or 0.90 x copy
       NLEV=72 step loop, 10 000 elements, 20 calls per launch  <= 0.115 ms per call."""
-    import torch
-    import tinman_sandbox_amd as tsa
-    lib = tsa.library().lib
-    dev = torch.device("cuda", 0)
-    st = torch.cuda.current_stream(dev)
-
-    def best_ms(fn, per_block=30, blocks=3, spin=60, calls_per_fn=1):
-        for _ in range(spin):
-            fn()
-        out = []
-        for _ in range(blocks):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(st)
-            for _ in range(per_block):
-                fn()
-            e1.record(st)
-            torch.cuda.synchronize(dev)
-            out.append(e0.elapsed_time(e1) / (per_block * calls_per_fn))
-        return min(out)
-
     got = {}
-    lib.caar_set_adaptive_window(0)
-    try:
-        for np_, nlev, elems in ((4, 72, 10000), (4, 128, 12500), (8, 72, 20000)):
-            data = tsa.TestData().init_data(elems, np_, nlev, device=dev)
-            balg = tsa.algorithmic_bytes(np_, nlev) * elems
-            ms = best_ms(lambda: tsa.compute_and_apply_rhs(data, st))
-            got["np%d_nlev%d" % (np_, nlev)] = balg / (ms * 1e-3) / 8e12
-            if (np_, nlev) == (4, 72):
-                lib.caar_select_variant(4, 72, 1)
-                try:
-                    ms = best_ms(lambda: tsa.compute_and_apply_rhs(data, st), spin=10)
-                finally:
-                    lib.caar_select_variant(4, 72, 0)
-                got["np4_nlev72_all_streaming"] = balg / (ms * 1e-3) / 8e12
-                saved = (data.control.dt2, data.constants.eta_ave_w)
-                data.control.dt2, data.constants.eta_ave_w = 1.0e-6, 0.0   # timing only: keeps hundreds of leap-frog steps finite
-                got["np4_nlev72_step_loop_ms_per_call"] = best_ms(lambda: tsa.compute_and_apply_rhs_steps(data, 20, True, st),
-                                                                  per_block=4, spin=3, calls_per_fn=20)
-                data.control.dt2, data.constants.eta_ave_w = saved
-            del data
-            torch.cuda.empty_cache()
-    finally:
-        lib.caar_set_adaptive_window(1)
-        lib.caar_adaptive_window_reset()
-    print("performance guard:", {k: round(v, 4) for k, v in got.items()})
-    assert got["np4_nlev72"] >= 0.84, got
-    assert got["np4_nlev72_all_streaming"] >= 0.74, got
-    assert got["np4_nlev128"] >= 0.78, got
-    assert got["np8_nlev72"] >= 0.74, got
-    assert got["np4_nlev72_step_loop_ms_per_call"] <= 0.115, got
+    for np_, nlev, elems, extra in ((4, 72, 10000, ["--twin", "--steps"]), (4, 128, 12500, []), (8, 72, 20000, [])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "perf_guard.py"), "--np", str(np_), "--nlev", str(nlev),
+                            "--elems", str(elems)] + extra, capture_output=True, text=True, timeout=600, env=_clean_env())
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        got["np%d_nlev%d" % (np_, nlev)] = _line(r.stdout)
+    print("performance guard:", json.dumps(got))
+    a, b, c = got["np4_nlev72"], got["np4_nlev128"], got["np8_nlev72"]
+    assert a["frac"] >= 0.84 or a["over_copy"] >= 1.03, a
+    assert a["all_streaming_frac"] >= 0.74 or a["all_streaming_over_copy"] >= 0.91, a
+    assert a["step_loop_ms_per_call"] <= 0.115, a
+    assert b["frac"] >= 0.78 or b["over_copy"] >= 0.96, b
+    assert c["frac"] >= 0.74 or c["over_copy"] >= 0.90, c
+    # ... and floors no box has come near, whatever its copy rate
+    assert a["frac"] >= 0.72 and b["frac"] >= 0.68 and c["frac"] >= 0.64, got

@@ -686,9 +686,10 @@ def test_adaptive_cache_window_changes_the_policy_not_the_results(nlev):
         for _ in range(130):
             tsa.compute_and_apply_rhs(a)
         torch.cuda.synchronize()
-        tsa.compute_and_apply_rhs(a)      # (collects the events of the probe)
+        for _ in range(8):                # (the tuner looks at a finished probe's events at its next slot: within 8 calls)
+            tsa.compute_and_apply_rhs(a)
         lib.caar_set_adaptive_window(0)
-        for _ in range(131):
+        for _ in range(138):
             tsa.compute_and_apply_rhs(b)
         torch.cuda.synchronize()
     finally:

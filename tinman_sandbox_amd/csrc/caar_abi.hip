@@ -378,12 +378,14 @@ static int adaptive_window_policy(const CaarArrays* dev, int device, hipStream_t
       t->sample = stamp(t->sample_ev[0]) ? 1 : 0;
     }
   }
-  // how many of the following calls have nothing to do here: none while a probe runs or a sample is open, else up to the
-  // next sample slot or the first probe, whichever comes first
+  // how many of the following calls have nothing to do here: none while a probe's calls run or a sample's second stamp is
+  // due; else up to the next sample slot or the first probe, whichever comes first.  (Also while a sample or a finished probe
+  // only WAITS for its last event: a host that enqueues far ahead of the GPU would otherwise come here on every call until
+  // the GPU has caught up; the completion is looked at again at the next slot.)
   long long grant = 0;
-  if (t->step == 0 && t->sample == 0) {
+  if ((t->step == 0 && t->sample != 1) || t->step == 2 * kHalf + 2) {
     grant = WindowTuner::kSampleEvery - 1 - t->calls % WindowTuner::kSampleEvery;
-    if (t->probes == 0) {
+    if (t->step == 0 && t->probes == 0) {
       const long long to_first = WindowTuner::kFirstProbe - 1 - t->since_decision;
       if (to_first < grant) grant = to_first < 0 ? 0 : to_first;
     }
