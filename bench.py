@@ -232,7 +232,7 @@ def measure_config(np_, nlev, elems, steps, warmup):
     j = json.loads(line[-1])
     roof = j["roofline"]
     return {"workload": "NP=%d NLEV=%d num_elems=%d" % (np_, nlev, elems), "kernel_ms": roof["kernel_ms"],
-            "traffic": roof["traffic"], "traffic_source": TRAFFIC_SOURCE,
+            "traffic": roof["traffic"], "traffic_source": roof.get("traffic_source", TRAFFIC_SOURCE),
             "element_updates_per_s": elems / (roof["kernel_ms"] * 1e-3), "achieved_GBs": roof["achieved"],
             "frac_of_hbm_peak": roof["frac"], "achieved_all_streaming_GBs": roof.get("achieved_all_streaming"),
             "algorithmic_bytes_per_element": roof["algorithmic_bytes_per_element"], "kernel": j["config"]["kernel"],
@@ -328,15 +328,19 @@ def own_traffic_skeleton(tsa, torch, data, dev, np_, nlev, elems):
     return best
 
 
-def static_traffic(np_, nlev, elems):
+def static_traffic(np_, nlev, elems, with_source=False):
     """HBM bytes per launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate passes, corrected as MI355X_MICROARCH.md prescribes).  NOT measured in this run: counters
+    separate passes, corrected as MI355X_MICROARCH.md prescribes; profiles/hbm_traffic.json, built by
+    tools/make_hbm_traffic.py from the newest round's passes).  NOT measured in this run: counters
     need the profiler around the process."""
     try:
         j = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-        return j.get("np%d_nlev%d_e%d" % (np_, nlev, elems), {}).get("hbm_bytes_per_launch")
+        row = j.get("np%d_nlev%d_e%d" % (np_, nlev, elems), {})
+        if with_source:
+            return row.get("hbm_bytes_per_launch"), row.get("source"), row.get("kernel")
+        return row.get("hbm_bytes_per_launch")
     except Exception:
-        return None
+        return (None, None, None) if with_source else None
 
 
 TRAFFIC_SOURCE = ("static: profiles/hbm_traffic.json (rocprofv3 --pmc passes committed with the repo; "
@@ -935,7 +939,8 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": static_traffic(args.np_, args.nlev, mine),
-            "traffic_source": TRAFFIC_SOURCE,
+            "traffic_source": TRAFFIC_SOURCE + ("; this configuration's passes: %s, kernel %s" % static_traffic(
+                args.np_, args.nlev, mine, True)[1:] if static_traffic(args.np_, args.nlev, mine) else ""),
             "algorithmic_bytes_per_element": balg,
             "elements_per_launch": mine,
             "kernel_ms": kernel_ms_max,
