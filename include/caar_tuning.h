@@ -37,7 +37,7 @@ int caar_set_xcd_chunked(int on);
  * on the same arrays finds them in the cache instead of in HBM (one read and one write saved per
  * byte and call).  Default 224 MiB (best of a sweep: flat from 192 to 240 MiB); 0 makes every access streaming.  Same
  * results either way.  Process-wide, atomic, read once per launch (as the variant selection).
- * The window is a budget of the DEVICE, not of a launch (ABI 5): which elements are kept is a property of the element's
+ * The window is a budget of the DEVICE, not of a launch (since ABI 5): which elements are kept is a property of the element's
  * index in the arrays (an evenly spread subset of dims->num_elems), so launches on sub-ranges [nets, nete) of one array
  * set — HOMME's horizontal OpenMP threads (data_structures.hpp:58-69), one after the other or side by side on several
  * streams — together keep what one launch over everything keeps.  Contexts (caar_create) on one device share the window
@@ -46,7 +46,7 @@ int caar_set_xcd_chunked(int on);
 #define CAAR_CACHE_WINDOW_DEFAULT (224LL << 20)
 int caar_set_cache_window(long long bytes);
 long long caar_get_cache_window(void);
-/* Adaptive window (default on; ABI 5).  Whether the window pays depends on what the host runs BETWEEN two calls: kept
+/* Adaptive window (default on; since ABI 5).  Whether the window pays depends on what the host runs BETWEEN two calls: kept
  * accumulators are worth +13 % when the next call finds them (the routine replayed, or alternated with kernels that
  * stream), and -2 % when a neighbour with the default cache policy has evicted them.  The library therefore measures:
  * per array set (keyed on elem_derived_vn0), whole-range launches of a hybrid-policy kernel are now and then bracketed

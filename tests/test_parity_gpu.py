@@ -232,7 +232,7 @@ def test_context_api_roundtrip(oracle):
 
 
 def test_contexts_on_one_device_share_the_cache_window():
-    """The hybrid policy's window is a budget of the device (include/caar.h, ABI 5): one context has all of it, two contexts
+    """The hybrid policy's window is a budget of the device (include/caar_tuning.h): one context has all of it, two contexts
     split it in proportion to their sizes, and a destroyed context gives its part back."""
     import ctypes as C
     from tinman_sandbox_amd import caar as m
