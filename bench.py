@@ -147,9 +147,11 @@ def cpu_baseline(np_, nlev, seconds, elems=10000):
     one_med = sorted(one)[1]
 
     # (b) `cores` threads: slabs of the same data set
-    def threaded(nthreads):
+    def threaded(nthreads, total_updates=None):
         per_thread = -(-elems // nthreads)
         reps = max(3, int(round(seconds / (one_med * per_thread / elems))))
+        if total_updates is not None:   # a bounded sample: the same number of element updates as the `cores` leg made
+            reps = max(2, -(-int(total_updates) // (nthreads * per_thread)))
         runners = [make_runner(per_thread) for _ in range(nthreads)]
         for r in runners:
             r()  # warm-up call (touches the memory)
@@ -178,11 +180,13 @@ def cpu_baseline(np_, nlev, seconds, elems=10000):
     all_n = len(os.sched_getaffinity(0))
     quota = cgroup_cpu_quota()
     if all_n > cores:
-        a_per, a_reps, a_wall = threaded(all_n)
+        a_per, a_reps, a_wall = threaded(all_n, total_updates=cores * per_thread * reps)
         all_threads = {"value": all_n * a_per * a_reps / a_wall, "cores": all_n, "elements_per_thread": a_per, "calls": a_reps,
                        "wall_seconds": a_wall, "cgroup_cpu_quota": quota,
-                       "note": ("%d threads time-sharing a cgroup quota of %.1f CPUs: not a whole-box figure, none can be measured "
-                                "from inside this job" % (all_n, quota)) if quota is not None and quota < all_n else
+                       "note": ("%d threads time-sharing a cgroup quota of %.1f CPUs (oversubscribed and throttled: slower than the "
+                                "%d-thread leg): not a whole-box figure, none can be measured from inside this job; the sample is "
+                                "the same number of element updates as the %d-thread leg made" % (all_n, quota, cores, cores))
+                               if quota is not None and quota < all_n else
                                "every hardware thread in the affinity mask; an 8-GPU node shares them between its 8 GPUs, so "
                                "the per-GPU comparison is `value` (%d threads)" % cores}
     else:
