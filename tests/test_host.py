@@ -251,3 +251,15 @@ def test_shipped_code_object_holds_what_design_says():
         k = by_name[name]
         assert k["vgprs"] <= 256 and k["vgpr_spills"] == 0 and k["lds_bytes"] <= lds_max, k
     assert any(n.startswith("caar_np4_steps_kernel<72,") for n in by_name) and any(n.startswith("caar_np8_steps_kernel<72,") for n in by_name)
+
+
+def test_window_tuner_state_machine_under_a_fake_clock(tmp_path):
+    """csrc/caar_window_tuner.h is free of HIP: tests/window_tuner_sim.cpp drives the adaptive cache window's state machine
+    with a simulated device (replaying host, evicting neighbour, a pattern change, a discarded probe, a host that enqueues
+    300 launches ahead, ties) and checks the decisions, when they are made, and how rarely a launch needs the slow path."""
+    import subprocess
+    exe = str(tmp_path / "window_tuner_sim")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "tinman_sandbox_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "window_tuner_sim.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr

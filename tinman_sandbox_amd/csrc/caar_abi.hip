@@ -15,6 +15,7 @@
 #include "../../include/caar.h"
 #include "../../include/caar_tuning.h"
 #include "caar_kernel_args.h"
+#include "caar_window_tuner.h"
 
 namespace caar {
 extern KernelVariant kNp4Nlev72[];
@@ -197,10 +198,8 @@ static LaunchChoice launch_choice(const Config* cfg) {
 // Events are recorded and queried under the mutex only, so a reset / LRU restart can never destroy an event another thread
 // is about to record.
 namespace caar {
+// One array set: the HIP-free state machine (caar_window_tuner.h) + what is published for lock-free readers + its HIP events.
 struct WindowTuner {
-  static constexpr int kFirstProbe = 48, kWarm = 3, kMeas = 4, kHalf = kWarm + kMeas, kReprobe = 96, kReprobeWindow = 4096, kSampleEvery = 8;
-  static constexpr int kProbeEvents = 2 * kHalf + 1;  // one in front of every probe call + one in front of the call after
-  static constexpr double kDrift = 0.03, kTie = 0.003;
   // published, read lock-free (a reader that races with a restart may see another set's policy for one call: both policies
   // compute the same thing)
   std::atomic<const void*> key{nullptr};  // CaarArrays::elem_derived_vn0 of the set
@@ -208,28 +207,33 @@ struct WindowTuner {
   std::atomic<int> use_window{1};
   std::atomic<long long> idle{0};  // whole-range calls that may still pass without the mutex
   // everything below: under WindowTuners::mu
-  long long calls = 0, since_decision = 0, probes = 0, last_use = 0;
-  long long idle_granted = 0;                  // what `idle` was last set to: that many calls went by uncounted
-  double ms_window = 0.0, ms_streaming = 0.0;  // medians of the last probe (call-to-call times)
-  double base_ms = 0.0, cur_ms = 0.0;          // the current policy's call-to-call time: at the decision / smoothed since
-  // probe: step 0 = idle; 1 .. 2 kHalf = that call of the probe is next; 2 kHalf + 1 = the closing event is next;
-  // 2 kHalf + 2 = all events recorded, waiting for them to complete
-  int step = 0, probe_first = 0 /* policy of the probe's first half */;
-  hipEvent_t probe_ev[kProbeEvents] = {};
-  hipEvent_t sample_ev[2] = {};
-  int sample = 0;  // 0 idle, 1 = first event recorded at the previous call, 2 = both recorded, waiting
-  bool broken = false;
+  WindowTunerState st;
+  long long last_use = 0;
+  hipEvent_t ev[WindowTunerState::kSlots] = {};
 
   void restart(const void* k, int dev) {  // (the events are kept for the next set: creating them is the expensive part)
     key.store(nullptr, std::memory_order_relaxed);
-    calls = since_decision = probes = last_use = idle_granted = 0;
-    ms_window = ms_streaming = base_ms = cur_ms = 0.0;
-    step = probe_first = sample = 0;
-    broken = false;
+    st.reset();
+    last_use = 0;
     use_window.store(1, std::memory_order_relaxed);
     idle.store(0, std::memory_order_relaxed);
     device.store(dev, std::memory_order_relaxed);
     key.store(k, std::memory_order_release);
+  }
+};
+// the state machine's view of the tuner's HIP events on the launch stream
+struct HipStampBackend {
+  WindowTuner* t;
+  hipStream_t stream;
+  bool stamp(int slot) {
+    hipEvent_t& e = t->ev[slot];
+    if (!e && hipEventCreate(&e) != hipSuccess) e = nullptr;
+    return e && hipEventRecord(e, stream) == hipSuccess;
+  }
+  bool ready(int slot) { return t->ev[slot] && hipEventQuery(t->ev[slot]) == hipSuccess; }
+  bool elapsed(int a, int b, float* ms) {
+    *ms = 0.f;
+    return t->ev[a] && t->ev[b] && hipEventElapsedTime(ms, t->ev[a], t->ev[b]) == hipSuccess && *ms > 0.f;
   }
 };
 struct WindowTuners {
@@ -246,15 +250,6 @@ static WindowTuner* find_tuner(WindowTuners* all, const void* key, int device) {
   for (auto& x : all->t)
     if (x.key.load(std::memory_order_acquire) == key && x.device.load(std::memory_order_relaxed) == device) return &x;
   return nullptr;
-}
-static double median_of(float* v, int n) {
-  for (int i = 1; i < n; ++i)
-    for (int j = i; j > 0 && v[j] < v[j - 1]; --j) {
-      const float t = v[j];
-      v[j] = v[j - 1];
-      v[j - 1] = t;
-    }
-  return n % 2 ? v[n / 2] : 0.5 * (v[n / 2 - 1] + v[n / 2]);
 }
 // forget the set whose derived_vn0 lies at `key` (its memory is being released: a later allocation at the same address
 // must not inherit its policy and counters); caar_arrays_free and caar_destroy call this
@@ -301,97 +296,11 @@ static int adaptive_window_policy(const CaarArrays* dev, int device, hipStream_t
   }
   t->last_use = ++all->tick;
   if (capturing) return t->use_window.load(std::memory_order_relaxed);  // (idle stays <= 0: the next plain call comes here again)
-  constexpr int kHalf = WindowTuner::kHalf;
-  auto stamp = [&](hipEvent_t& e) -> bool {  // record `e` in front of this call
-    if (!e && hipEventCreate(&e) != hipSuccess) e = nullptr;
-    if (!e || hipEventRecord(e, stream) != hipSuccess) {
-      t->broken = true;
-      return false;
-    }
-    return true;
-  };
-  auto elapsed = [&](hipEvent_t a, hipEvent_t b, float* ms) {
-    *ms = 0.f;
-    return hipEventElapsedTime(ms, a, b) == hipSuccess && *ms > 0.f;
-  };
-  // the calls that went by on the fast path since the mutex was last held, and this one
-  t->calls += t->idle_granted + 1;
-  t->since_decision += t->idle_granted + 1;
-  t->idle_granted = 0;
-  int use = t->use_window.load(std::memory_order_relaxed);
-  // the passive sample of the current policy: completed?
-  if (t->sample == 2 && hipEventQuery(t->sample_ev[1]) == hipSuccess) {
-    float ms;
-    if (elapsed(t->sample_ev[0], t->sample_ev[1], &ms) && t->step == 0) t->cur_ms = t->cur_ms > 0.0 ? 0.75 * t->cur_ms + 0.25 * ms : ms;
-    t->sample = 0;
-  }
-  // a probe whose events are all recorded: decide once the last one has completed
-  if (t->step == 2 * kHalf + 2 && (t->broken || hipEventQuery(t->probe_ev[2 * kHalf]) == hipSuccess)) {
-    float m[2][WindowTuner::kMeas];
-    bool ok = !t->broken;
-    for (int h = 0; h < 2 && ok; ++h)
-      for (int i = 0; i < WindowTuner::kMeas && ok; ++i) {
-        const int c = h * kHalf + WindowTuner::kWarm + i;  // 0-based probe call: from its start to the next call's start
-        ok = elapsed(t->probe_ev[c], t->probe_ev[c + 1], &m[h][i]);
-      }
-    if (ok) {
-      const double first = caar::median_of(m[0], WindowTuner::kMeas), second = caar::median_of(m[1], WindowTuner::kMeas);
-      t->ms_window = t->probe_first ? first : second;
-      t->ms_streaming = t->probe_first ? second : first;
-      use = t->ms_window <= t->ms_streaming * (1.0 + WindowTuner::kTie) ? 1 : 0;
-      t->use_window.store(use, std::memory_order_relaxed);
-      t->base_ms = t->cur_ms = use ? t->ms_window : t->ms_streaming;
-      ++t->probes;
-    }
-    t->step = 0;
-    t->broken = false;
-    t->since_decision = 0;  // (also after a probe that had to be discarded: the first-probe test below re-arms on it)
-    t->sample = 0;
-  }
+  caar::HipStampBackend be{t, stream};
+  const int policy = t->st.step(be);
   (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error code
-  if (t->step == 0) {
-    // (a first probe that was discarded — an event could not be created, a non-positive interval — leaves probes == 0 and
-    // since_decision reset: it is tried again kFirstProbe calls later, not never)
-    const bool first = t->probes == 0 && t->since_decision >= WindowTuner::kFirstProbe;
-    const bool drift = t->probes > 0 && t->base_ms > 0.0 && t->cur_ms > t->base_ms * (1.0 + WindowTuner::kDrift) && t->since_decision > 24;
-    // (while the window is the policy a re-probe costs seven all-streaming calls, so it is rare: it only guards against a
-    // first probe that was taken during a fresh process's ramp-up, which favours whichever policy ran second)
-    const bool again = t->probes > 0 && t->since_decision >= (use ? WindowTuner::kReprobeWindow : WindowTuner::kReprobe);
-    if (first || drift || again) {
-      t->step = 1;
-      t->sample = 0;
-      t->probe_first = use ? 0 : 1;  // the OTHER policy first, the current one second
-    }
-  }
-  int policy = use;
-  if (t->step >= 1 && t->step <= 2 * kHalf) {
-    const int s = t->step++;  // 1 .. 2 kHalf
-    (void)stamp(t->probe_ev[s - 1]);
-    policy = (s - 1) / kHalf == 0 ? t->probe_first : 1 - t->probe_first;
-  } else if (t->step == 2 * kHalf + 1) {  // the call after the probe: its start closes the last measured interval
-    (void)stamp(t->probe_ev[2 * kHalf]);
-    t->step = 2 * kHalf + 2;
-  } else if (t->step == 0) {
-    if (t->sample == 1) {
-      t->sample = stamp(t->sample_ev[1]) ? 2 : 0;
-    } else if (t->sample == 0 && t->calls % WindowTuner::kSampleEvery == 0) {
-      t->sample = stamp(t->sample_ev[0]) ? 1 : 0;
-    }
-  }
-  // how many of the following calls have nothing to do here: none while a probe's calls run or a sample's second stamp is
-  // due; else up to the next sample slot or the first probe, whichever comes first.  (Also while a sample or a finished probe
-  // only WAITS for its last event: a host that enqueues far ahead of the GPU would otherwise come here on every call until
-  // the GPU has caught up; the completion is looked at again at the next slot.)
-  long long grant = 0;
-  if ((t->step == 0 && t->sample != 1) || t->step == 2 * kHalf + 2) {
-    grant = WindowTuner::kSampleEvery - 1 - t->calls % WindowTuner::kSampleEvery;
-    if (t->step == 0 && t->probes == 0) {
-      const long long to_first = WindowTuner::kFirstProbe - 1 - t->since_decision;
-      if (to_first < grant) grant = to_first < 0 ? 0 : to_first;
-    }
-  }
-  t->idle_granted = grant;
-  t->idle.store(grant, std::memory_order_relaxed);
+  t->use_window.store(t->st.use_window, std::memory_order_relaxed);
+  t->idle.store(t->st.idle_granted, std::memory_order_relaxed);
   return policy;
 }
 
@@ -399,11 +308,10 @@ static int adaptive_window_policy(const CaarArrays* dev, int device, hipStream_t
 // the hybrid policy could keep for each (vn0, omega_p, eta_dot_dpdn of every element).  One context gets all of it.
 namespace caar {
 struct DeviceShares {
-  std::mutex mu;
-  long long keepable[64] = {};  // per device: sum over live contexts of num_elems * keepable bytes per element
+  std::atomic<long long> keepable[64];  // per device: sum over live contexts of num_elems * keepable bytes per element
 };
 static DeviceShares* device_shares() {
-  static DeviceShares* s = new DeviceShares();  // never destroyed (contexts may be released from finalisers at exit)
+  static DeviceShares* s = new DeviceShares();  // never destroyed (contexts may be released from finalisers at exit); zero-initialised
   return s;
 }
 static long long keepable_bytes(const CaarDims& d) {
@@ -412,16 +320,12 @@ static long long keepable_bytes(const CaarDims& d) {
 }
 static void device_shares_add(int device, long long bytes) {
   if (device < 0 || device >= 64) return;
-  DeviceShares* s = device_shares();
-  std::lock_guard<std::mutex> g(s->mu);
-  s->keepable[device] += bytes;
+  device_shares()->keepable[device].fetch_add(bytes, std::memory_order_relaxed);
 }
-// this context's part of `window`
+// this context's part of `window` (lock-free: read on every caar_run)
 static long long device_share_of(int device, const CaarDims& d, long long window) {
   if (device < 0 || device >= 64) return window;
-  DeviceShares* s = device_shares();
-  std::lock_guard<std::mutex> g(s->mu);
-  const long long mine = keepable_bytes(d), all = s->keepable[device];
+  const long long mine = keepable_bytes(d), all = device_shares()->keepable[device].load(std::memory_order_relaxed);
   if (all <= mine || all <= 0) return window;
   return (long long)((double)window * ((double)mine / (double)all));
 }
@@ -534,9 +438,9 @@ int caar_adaptive_window_state(const double* vn0_dev, double* ms_window, double*
   std::lock_guard<std::mutex> g(all->mu);
   for (auto& t : all->t)
     if (vn0_dev && t.key.load(std::memory_order_relaxed) == (const void*)vn0_dev) {
-      if (ms_window) *ms_window = t.ms_window;
-      if (ms_streaming) *ms_streaming = t.ms_streaming;
-      if (probes) *probes = t.probes;
+      if (ms_window) *ms_window = t.st.ms_window;
+      if (ms_streaming) *ms_streaming = t.st.ms_streaming;
+      if (probes) *probes = t.st.probes;
       return t.use_window.load(std::memory_order_relaxed);
     }
   return -1;
