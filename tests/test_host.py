@@ -263,3 +263,32 @@ def test_window_tuner_state_machine_under_a_fake_clock(tmp_path):
                     os.path.join(ROOT, "tests", "window_tuner_sim.cpp"), "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
+def test_shipped_headline_kernels_are_the_measured_instruction_streams():
+    """the kernels' speed is pinned to what one hipcc makes of a 17-parameter template.  The GPU guard
+    (tests/test_bench_gpu.py::test_performance_lower_bounds) catches a slow build on the GPU; this one catches a CHANGED build on
+    the CPU: the instruction streams of the kernels a default launch of the BASELINE configurations reaches (tools/isa_hash.py:
+    md5 over the disassembly, addresses stripped) must be the ones the committed measurements were taken with
+    (tests/golden/isa_fingerprints.json).  A deliberate change of a kernel re-measures (tools/perf_guard.py, bench.py) and then
+    refreshes the file with `python tools/isa_hash.py --write-golden`.  Another compiler: skipped, the GPU guard decides."""
+    import importlib.util
+    import json
+    import shutil
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") or shutil.which("c++filt") is None:
+        pytest.skip("llvm-objdump / c++filt not available")
+    tools = os.path.join(ROOT, "tools")
+    sys_path_added = tools not in __import__("sys").path
+    if sys_path_added:
+        __import__("sys").path.insert(0, tools)
+    spec = importlib.util.spec_from_file_location("isa_hash", os.path.join(tools, "isa_hash.py"))
+    ih = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ih)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "isa_fingerprints.json")))
+    if ih.compiler_id() != gold["compiler"]:
+        pytest.skip("built by another compiler than the fingerprints were taken with: %s" % ih.compiler_id())
+    tbuild.build_library()
+    got = ih.demangled_hashes(os.path.join(ROOT, "tinman_sandbox_amd", "csrc", "libcaar_hip.so"))
+    assert set(ih.GUARDED) == set(gold["kernels"])
+    changed = [k for k, v in gold["kernels"].items() if k not in got or got[k][0] != v["md5"]]
+    assert not changed, "instruction streams changed (re-measure, then `python tools/isa_hash.py --write-golden`): %s" % changed

@@ -43,9 +43,38 @@ def kernel_hashes(path):
     return out
 
 
-if __name__ == "__main__":
-    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tinman_sandbox_amd", "csrc", "libcaar_hip.so")
+def demangled_hashes(lib):
+    """{demangled kernel name (as the variant tables spell it): (md5, instruction count)}"""
     hs = kernel_hashes(lib)
     names = subprocess.run(["c++filt"] + list(hs), capture_output=True, text=True).stdout.splitlines()
-    for mangled, dem in sorted(zip(hs, names), key=lambda x: x[1]):
-        print("%s %6d  %s" % (hs[mangled][0], hs[mangled][1], dem.replace("void caar::", "").split("(caar::")[0]))
+    return {dem.replace("void caar::", "").split("(caar::")[0]: hs[m] for m, dem in zip(hs, names)}
+
+
+def compiler_id():
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout
+    return " | ".join(ln.strip() for ln in out.splitlines()[:2])
+
+
+# the kernels a default launch of the BASELINE configurations reaches (single calls, all-streaming twins, step loops)
+GUARDED = ("caar_np4_kernel<72, 5, 1, true, 2, 0, false, false, false, 8, 0>",
+           "caar_np4_kernel<72, 5, 1, true, 1, 0, false, false, false, 8, 0>",
+           "caar_np4_kernel<128, 8, 2, true, 2, 0, false, false, false, 8, 27>",
+           "caar_np4_kernel<128, 8, 2, true, 1, 0, false, false, false, 8, 27>",
+           "caar_np8_kernel<72, 9, 1, true, true, false, false, false, false, true, 2>",
+           "caar_np4_steps_kernel<72, 5, 2, true, 0, 0, 0, 4, 0>",
+           "caar_np4_steps_kernel<128, 4, 2, true, 0, 0, 0, 3, 0>",
+           "caar_np8_steps_kernel<72, 9, 1, true, false, 2>")
+
+
+if __name__ == "__main__":
+    args = [x for x in sys.argv[1:] if not x.startswith("--")]
+    lib = args[0] if args else os.path.join(ROOT, "tinman_sandbox_amd", "csrc", "libcaar_hip.so")
+    hs = demangled_hashes(lib)
+    if "--write-golden" in sys.argv:   # tests/golden/isa_fingerprints.json: what tests/test_host.py holds the build against
+        import json
+        out = {"compiler": compiler_id(), "kernels": {k: {"md5": hs[k][0], "instructions": hs[k][1]} for k in GUARDED}}
+        json.dump(out, open(os.path.join(ROOT, "tests", "golden", "isa_fingerprints.json"), "w"), indent=1)
+        print("wrote tests/golden/isa_fingerprints.json for", out["compiler"])
+    else:
+        for dem in sorted(hs):
+            print("%s %6d  %s" % (hs[dem][0], hs[dem][1], dem))
