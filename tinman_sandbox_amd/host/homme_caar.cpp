@@ -312,6 +312,12 @@ void sync_to_device(const TestData& data) {
   std::lock_guard<std::mutex> g(r.mu);
   if (!resident_holds(r, data)) return;
   resident_wait(r);
+  if (r.res.host_stale) {
+    // the host's copies of the mutated arrays are older than the device's: uploading them would undo the calls made since
+    // the last sync_to_host.  The order is sync_to_host -> change the arrays -> sync_to_device; anything else fails loudly.
+    std::fprintf(stderr, "caar: sync_to_device: the host arrays are stale (call sync_to_host before changing them)\n");
+    std::abort();
+  }
   check(caar_upload(r.res.ctx, &r.res.key, 0, r.res.ne), "caar_upload");
   check(caar_sync(r.res.ctx), "caar_sync");
   r.res.host_stale = false;

@@ -35,7 +35,8 @@ void compute_and_apply_rhs(TestData& data);
 // surface: its callee holds no state).
 void release_host_mapping();
 // Resident mode: bring the host arrays up to date (the seven arrays the path mutates) / send the host's arrays to the
-// device again after the host changed them.  No-ops in mapped mode and for arrays the shim holds no device copy of.
+// device again after the host changed them (in that order: sync_to_host, change, sync_to_device — sync_to_device on a stale
+// host copy aborts rather than undo the calls made since).  No-ops in mapped mode and for arrays the shim holds no device copy of.
 // (cf. sync_to_host / sync_to_device of the reference's Kokkos variants, level_vectorized_ppscan/Utility.hpp)
 void sync_to_host(TestData& data);
 void sync_to_device(const TestData& data);
