@@ -7,7 +7,8 @@
 //   (2) before sync_to_host the host's copy of the np1 state is still the input (the documented staleness);
 //   (3) sync_to_device: a change the host makes to its arrays reaches the device copy;
 //   (4) a second set of arrays takes the device copy over and the first set's results are written back first;
-//   (5) shim_stats counts the calls.
+//   (5) shim_stats counts the calls;
+//   (6) (argv[2] = "misuse") sync_to_device on a stale host copy aborts.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -49,6 +50,15 @@ int main(int argc, char** argv) {
   const int ne = argc > 1 ? std::atoi(argv[1]) : 23, calls = 3;
   num_elems = ne;
   int bad = 0;
+  if (argc > 2 && std::strcmp(argv[2], "misuse") == 0) {
+    // sync_to_device while the host copy is stale would undo the call: the shim must abort, not upload
+    TestData m;
+    m.init_data();
+    compute_and_apply_rhs(m);
+    sync_to_device(m);
+    std::printf("sync_to_device on a stale host copy returned\nFAILED\n");
+    return 1;
+  }
 
   // the same loop through DeviceSession: what the shim must reproduce
   TestData want_d;

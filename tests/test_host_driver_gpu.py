@@ -274,6 +274,8 @@ def test_shim_resident_mode_semantics(tmp_path):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
     r = subprocess.run([exe, "23"], capture_output=True, text=True, timeout=300, env=_env())
     assert r.returncode == 1 and "not in resident mode" in r.stdout   # the mode is opt-in
+    r = subprocess.run([exe, "23", "misuse"], capture_output=True, text=True, timeout=300, env=_env(CAAR_SHIM_RESIDENT="1"))
+    assert r.returncode != 0 and "host arrays are stale" in r.stderr and "FAILED" not in r.stdout, r.stdout + r.stderr
 
 
 def test_driver_host_arrays_modes_agree():
