@@ -671,8 +671,11 @@ static void fill_args_impl(caar::KernelArgs& k, const CaarDims* dims, const Caar
     // (data_structures.hpp:58-69), one after the other or side by side on several streams — keeps the same set, i.e. ONE
     // window per device, not one per launch (round 3 budgeted per launch: four sub-range launches claimed 4 x 224 MB of
     // a 256 MB cache)
-    k.cache_n = dims->num_elems;
-    k.cache_count = n <= 0 ? 0 : (n >= dims->num_elems ? dims->num_elems : (int)n);
+    const long long count = n <= 0 ? 0 : (n >= dims->num_elems ? dims->num_elems : n);
+    // c / n in 32.32 fixed point (element_is_cached multiplies instead of dividing); c == n: exactly 2^32, every element
+    const unsigned long long q = dims->num_elems > 0 ? (((unsigned long long)count << 32) / (unsigned long long)dims->num_elems) : 0ull;
+    k.cache_q_lo = (unsigned)(q & 0xffffffffull);
+    k.cache_q_hi = (unsigned)(q >> 32);
   }
   k.n0 = p->n0;
   k.np1 = p->np1;

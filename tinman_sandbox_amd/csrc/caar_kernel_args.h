@@ -42,10 +42,11 @@ struct KernelArgs {
   int nets;           // first element of this launch
   int nelem;          // elements in this launch
   int per_xcd;        // 0: element = nets + blockIdx.x; else XCD-chunked mapping (element_of_block)
-  int cache_count;    // hybrid cache policy: that many of the arrays' cache_n elements, spread evenly over the WHOLE
-  int cache_n;        // element range of the arrays (not over the launch), keep their accumulators in the memory-side
-                      // cache (0: none): launches on sub-ranges — one after the other or side by side on several
-                      // streams — together keep exactly the set one launch over everything keeps
+  // hybrid cache policy: cache_count of the arrays' cache_n elements, spread evenly over the WHOLE element range of the arrays
+  // (not over the launch), keep their accumulators in the memory-side cache (0: none) — launches on sub-ranges, one after the
+  // other or side by side on several streams, together keep exactly the set one launch over everything keeps.  The kernels
+  // get the ratio: floor(cache_count * 2^32 / cache_n), formed on the host (element_is_cached)
+  unsigned cache_q_lo, cache_q_hi;
   int n0, np1, nm1;
   int qn0;            // -1: dry
   int qsize_d, timelevels;
@@ -74,17 +75,31 @@ struct KernelArgs {
 __device__ __forceinline__ long long element_of_block(const KernelArgs& k, unsigned b) {
   if (k.per_xcd == 0) return (long long)k.nets + b;
   const unsigned x = b & 7u, s = b >> 3;
-  const long long e = (long long)x * k.per_xcd + s;
-  return (s < (unsigned)k.per_xcd && e < k.nelem) ? k.nets + e : -1;
+  const unsigned e = x * (unsigned)k.per_xcd + s;  // < 8 * per_xcd <= nelem + 7: 32-bit arithmetic is enough
+  return (s < (unsigned)k.per_xcd && e < (unsigned)k.nelem) ? (long long)k.nets + e : -1;
+}
+
+// First statement of a kernel: one field of every 64-byte line of the 256-byte kernel-argument block is needed HERE (an empty
+// asm that takes them as scalar inputs), so the compiler requests all four lines together at the top.  Left alone it requests
+// each line where the code first uses it: four scalar-cache misses one after the other in front of a workgroup's first load —
+// and that prologue is not hidden (two workgroups per CU): with the two 64-bit divisions that used to sit there as well it cost
+// 2 % of the headline (profiles/r05/fixedq_kbench.log, prologue_kbench.log).
+__device__ __forceinline__ void request_kernel_args(const KernelArgs& k) {
+  asm volatile("" ::"s"(k.D), "s"(k.v), "s"(k.vn0), "s"(k.timelevels));
 }
 
 // Hybrid cache policy: is element `ie` (its index in the arrays, 0 .. cache_n-1) one of the cache_count evenly
 // spread chosen ones?  (Bresenham: floor((ie+1)*c/n) > floor(ie*c/n).)  A property of the element, not of the
 // launch that happens to process it: the budget is the device's, however the host cuts the range into launches.
 __device__ __forceinline__ bool element_is_cached(const KernelArgs& k, long long ie) {
-  const unsigned long long c = (unsigned)k.cache_count, n = (unsigned)k.cache_n;
+  // floor((ie + 1) * c / n) > floor(ie * c / n) with c / n as the 32.32 fixed-point number q the host formed: two scalar
+  // multiplies instead of two 64-bit divisions (a v_rcp_f32 sequence of ~100 instructions in front of a workgroup's first
+  // load).  The subset differs from the exact Bresenham one by at most one element in count; what matters — an evenly spread
+  // subset that is a function of the element's index only — is unchanged.
   // (a hashed, pseudo-random pick of the same density was measured and is no better: docs/EXPERIMENTS.md A)
-  return c != 0 && ((unsigned long long)(ie + 1) * c) / n > ((unsigned long long)ie * c) / n;
+  const unsigned long long q = ((unsigned long long)k.cache_q_hi << 32) | k.cache_q_lo;
+  const unsigned long long e = (unsigned long long)ie;
+  return (((e + 1) * q) >> 32) > ((e * q) >> 32);
 }
 
 // 1/x for a normal, non-zero fp64 x: v_rcp_f64 seed + two Newton steps (5 instructions,
@@ -149,13 +164,13 @@ __device__ __forceinline__ KernelArgs reload_args() {
 #define CAAR_F(f) k.f = kp->f;
   CAAR_F(D) CAAR_F(Dinv) CAAR_F(fcor) CAAR_F(spheremp) CAAR_F(metdet) CAAR_F(rmetdet) CAAR_F(dp3d) CAAR_F(v) CAAR_F(T)
   CAAR_F(phis) CAAR_F(Qdp) CAAR_F(eta_dot_dpdn) CAAR_F(omega_p) CAAR_F(phi) CAAR_F(pecnd) CAAR_F(vn0) CAAR_F(Dvv)
-  CAAR_F(hybi) CAAR_F(vadv) CAAR_F(nets) CAAR_F(nelem) CAAR_F(per_xcd) CAAR_F(cache_count) CAAR_F(cache_n) CAAR_F(n0) CAAR_F(np1)
+  CAAR_F(hybi) CAAR_F(vadv) CAAR_F(nets) CAAR_F(nelem) CAAR_F(per_xcd) CAAR_F(cache_q_lo) CAAR_F(cache_q_hi) CAAR_F(n0) CAAR_F(np1)
   CAAR_F(nm1) CAAR_F(qn0) CAAR_F(qsize_d) CAAR_F(timelevels) CAAR_F(nlev) CAAR_F(dt2) CAAR_F(rrearth) CAAR_F(eta_ave_w)
   CAAR_F(rv_over_rd_m1) CAAR_F(Rgas) CAAR_F(kappa) CAAR_F(p_top)
 #undef CAAR_F
   return k;
 }
-static_assert(sizeof(KernelArgs) == 18 * 8 + 13 * 4 + 4 /* padding */ + 7 * 8, "reload_args lists every member of KernelArgs");
+static_assert(sizeof(KernelArgs) == 18 * 8 + 13 * 4 + 4 /* padding */ + 7 * 8 && sizeof(KernelArgs) == 256, "reload_args lists every member of KernelArgs");
 
 // -DCAAR_DEBUG builds (libcaar_hip_debug.so): the reference's only hot-path assertion, check_dp3d
 // (level_vectorized_ppscan/CaarFunctor.hpp:82-97: dp3d(np1) > 0 under !NDEBUG), as a device-side counter instead of an

@@ -177,7 +177,8 @@ struct Np4N0In {
 // Every STEPS call hands the same things on to the next one.
 template <int NLEV_T, int TPW, int MINW, bool MOIST, bool SNT, bool ANT, int PF, bool PERSIST, bool ETA_COND, bool VADV, int DYNW, int PARK = 0, bool STEPS = false, int CARRY_LDS = 0, int CARRY_IN = 0, int STORES = -1, int WAVES = 0>
 __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW, PARK, CARRY_LDS>& lds,
-                                                 Np4N0In<TPW>* carry = nullptr, int step_stores = 3, int tot_par = 0) {
+                                                 Np4N0In<TPW>* carry = nullptr, int step_stores = 3, int tot_par = 0,
+                                                 long long ie_known = -2) {
   // step_stores (uniform; STEPS only; else all; STORES >= 0: the same as a compile-time constant, for the hot loop):
   // bit 1 = store the np1 state (v, T, dp3d), bit 2 = store derived_phi.  The
   // step loop leaves them out where a later call of the same launch overwrites them and nothing reads them in between:
@@ -253,8 +254,10 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
   // (the even shapes keep the expression they always had: the headline kernels' code must not change with this option)
   const size_t wbase = UNEVEN ? (size_t)tile0 * 64 : (size_t)w * (TPW * 64);  // first point of this wave's tiles inside a field block
 
+  // ie_known (uniform; >= -1): the caller has already mapped this workgroup to its element (the hybrid kernel needs it to
+  // pick the code path, the step loop for its early exit): not formed a second time in front of the first loads
   long long ie_s = PERSIST ? (blockIdx.x < (unsigned)k.nelem ? (long long)k.nets + blockIdx.x : -1)
-                           : element_of_block(k, blockIdx.x);
+                           : (ie_known != -2 ? ie_known : element_of_block(k, blockIdx.x));
   if (ie_s < 0) return;  // padding block (uniform for the workgroup)
   unsigned eb = blockIdx.x;  // PERSIST: element counter relative to nets
 
@@ -728,15 +731,16 @@ __device__ __forceinline__ void caar_np4_element(const KernelArgs& k, Np4Lds<NLE
 //      kernel; the choice is uniform per workgroup.
 template <int NLEV_T, int TPW, int MINW, bool MOIST, int POL, int PF, bool PERSIST, bool ETA_COND, bool VADV = false, int DYNW = 8, int PARK = 0>
 __global__ __launch_bounds__(NLEV_T ? ((NLEV_T + 3) / 4 + TPW - 1) / TPW * 64 : DYNW * 64, MINW) void caar_np4_kernel(const KernelArgs k) {
+  request_kernel_args(k);
   __shared__ Np4Lds<NLEV_T, TPW, PERSIST, VADV, DYNW, PARK> lds;
   if constexpr (POL == 2) {
     static_assert(!PERSIST, "hybrid cache policy: non-persistent form only");
     const long long ie_s = element_of_block(k, blockIdx.x);
     if (ie_s < 0) return;
     if (element_is_cached(k, ie_s))
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, false, PF, PERSIST, ETA_COND, VADV, DYNW, PARK>(k, lds);
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, false, PF, PERSIST, ETA_COND, VADV, DYNW, PARK>(k, lds, nullptr, 3, 0, ie_s);
     else
-      caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, true, PF, PERSIST, ETA_COND, VADV, DYNW, PARK>(k, lds);
+      caar_np4_element<NLEV_T, TPW, MINW, MOIST, true, true, PF, PERSIST, ETA_COND, VADV, DYNW, PARK>(k, lds, nullptr, 3, 0, ie_s);
   } else {
     caar_np4_element<NLEV_T, TPW, MINW, MOIST, POL == 1, POL == 1, PF, PERSIST, ETA_COND, VADV, DYNW, PARK>(k, lds);
   }

@@ -456,6 +456,7 @@ __device__ __forceinline__ void caar_np8_element(const KernelArgs& k, Np8Lds<NLE
 
 template <int NLEV, int TPW, int MINW, bool MOIST, bool SNT, bool COEF_LDS, bool RELOAD_T, bool BATCH, bool VADV = false, bool MFMA = false, int LA = 1>
 __global__ __launch_bounds__(NLEV / TPW * 64, MINW) void caar_np8_kernel(const KernelArgs k) {
+  request_kernel_args(k);
   __shared__ Np8Lds<NLEV, TPW, BATCH, VADV, MFMA> lds;
   caar_np8_element<NLEV, TPW, MINW, MOIST, SNT, COEF_LDS, RELOAD_T, BATCH, VADV, MFMA, LA>(k, lds);
 }
