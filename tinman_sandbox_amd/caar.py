@@ -216,7 +216,11 @@ class CaarLibrary:
 
     def check(self, rc, what):
         if rc != 0:
-            raise CaarError("%s failed: rc=%d (%s)" % (what, rc, self.lib.caar_strerror(rc).decode()))
+            hint = ""
+            if rc == -2 and os.path.exists(os.path.join(_HERE, "csrc", "libcaar_hip_extra.so")) and "extra" not in LIB_PATH:
+                hint = ("; libcaar_hip_extra.so (CAAR_LIBRARY=extra) holds more: the Eulerian form beyond 128 levels, launch "
+                        "shapes specialised for NLEV 26, 30, 32, 60, 64, 80, 96")
+            raise CaarError("%s failed: rc=%d (%s)%s" % (what, rc, self.lib.caar_strerror(rc).decode(), hint))
 
 
 _LIB = None
